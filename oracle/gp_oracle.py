@@ -1,0 +1,420 @@
+"""CPU oracle for the BOSS.jl GP-posterior + acquisition hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import it.  The product path (boss.jl_amd/) never
+imports anything from oracle/ and fails loudly when the HIP library is missing.
+
+It is a plain numpy/scipy (OpenBLAS LAPACK) fp64 restatement of what the reference computes
+on this path.  Every function cites the reference file:line it follows (paths relative to
+/root/reference).  The reference delegates the arithmetic to packages that are NOT vendored
+under /root/reference:
+
+    AbstractGPs.jl   compat 0.5.21   (Project.toml:25)   posterior / logpdf / mean_and_var
+    KernelFunctions.jl (transitive, unpinned)            Matern32/52, SqExponential, ARD
+    Distances.jl       (transitive)                      pairwise Euclidean
+    Distributions.jl 0.25.109 / StatsFuns                Normal cdf/pdf
+
+so those parts restate the packages' published algorithms, anchored on the reference's call
+sites (src/models/gaussian_process.jl:199-248,279) and on src/models/gradient_gp.jl:323-361,403
+which spells the same algebra out in-repo.
+
+PARITY PIN STATUS: the reference is Julia; no Julia toolchain exists in this pipeline and the
+reference's tests hold NO golden posterior numbers (they are property / known-answer tests).
+The oracle is therefore pinned by (i) every known-answer and property test the reference holds
+for this path (tests/test_oracle_reference_pins.py), (ii) an independent 50-digit mpmath
+evaluation of the same formulas, (iii) scikit-learn's GaussianProcessRegressor as an independent
+third-party implementation.  Absolute numeric parity with AbstractGPs beyond that is UNPINNED.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import scipy.linalg as sla
+from scipy.special import erfc
+
+# src/models/gaussian_process.jl:5   const MIN_PARAM_VALUE = 1e-8
+MIN_PARAM_VALUE = 1e-8
+# src/models/gaussian_process.jl:13  const MAX_NEG_VAR = 1e-8
+MAX_NEG_VAR = 1e-8
+# AbstractGPs: `post(X*)` without a noise argument builds FiniteGP(f, x, Σy=1e-18)
+# (AbstractGPs/src/finite_gp_projection.jl default_σ² = 1e-18) -> var(post(X*)) adds it.
+PREDICT_JITTER = 1e-18
+
+MATERN32, MATERN52, SQEXP = 0, 1, 2
+KERNEL_NAMES = {"matern32": MATERN32, "matern52": MATERN52, "sqexp": SQEXP}
+
+_SQRT3 = math.sqrt(3.0)
+_SQRT5 = math.sqrt(5.0)
+_LOG2PI = math.log(2.0 * math.pi)
+
+
+class DomainError(ValueError):
+    """Mirror of Julia's DomainError thrown by `_clip_var` (gaussian_process.jl:191-193)."""
+
+
+class PosDefException(np.linalg.LinAlgError):
+    """Mirror of LinearAlgebra.PosDefException raised by `cholesky` on a non-PD matrix."""
+
+
+# --------------------------------------------------------------------------------------
+# kernels  (KernelFunctions.jl: Matern32Kernel / Matern52Kernel / SqExponentialKernel;
+#           reference use: src/deprecated.jl:34 default Matern52, examples/example.jl:88 Matern32,
+#           src/models/nonstationary_gp/nonstationary_gp.jl:438 GaussianKernel)
+# --------------------------------------------------------------------------------------
+def kappa(kernel: int, r: np.ndarray) -> np.ndarray:
+    """Radial profile of the base kernel on Euclidean distance r (KernelFunctions `kappa`)."""
+    if kernel == MATERN32:
+        s = _SQRT3 * r
+        return (1.0 + s) * np.exp(-s)
+    if kernel == MATERN52:
+        s = _SQRT5 * r
+        return (1.0 + s + s * s / 3.0) * np.exp(-s)
+    if kernel == SQEXP:
+        return np.exp(-0.5 * r * r)
+    raise ValueError(f"unknown kernel id {kernel}")
+
+
+def discrete_round(X: np.ndarray, discrete: Optional[Sequence[bool]]) -> np.ndarray:
+    """src/utils/utils.jl `discrete_round` + src/models/utils/kernels.jl:56-59 (DiscreteKernel):
+    flagged dims of BOTH kernel arguments are rounded (Julia `round` = half-to-even = np.rint)."""
+    if discrete is None:
+        return X
+    discrete = np.asarray(discrete, dtype=bool)
+    if not discrete.any():
+        return X
+    X = np.array(X, dtype=np.float64, copy=True)
+    X[discrete, :] = np.rint(X[discrete, :])
+    return X
+
+
+def scaled_distance(Xa: np.ndarray, Xb: np.ndarray, lengthscale: np.ndarray,
+                    form: str = "direct") -> np.ndarray:
+    """Pairwise Euclidean distance of ARD-scaled columns, r_ij = ||(xa_i - xb_j) ./ λ||.
+
+    `with_lengthscale(kernel, λ::Vector)` = kernel ∘ ARDTransform(1 ./ λ)
+    (gaussian_process.jl:243), i.e. inputs are multiplied by inv(λ) first.
+    form="direct": sum of squared differences (what the HIP kernels do; most accurate).
+    form="gemm":   ||a||²+||b||²-2a·b, clamped at 0 — the Distances.jl `pairwise(Euclidean())`
+                   formulation KernelFunctions uses for ColVecs inputs (threshold 0).
+    The two differ by O(eps·||x/λ||²) in r²; tests quantify it.
+    """
+    inv = 1.0 / np.asarray(lengthscale, dtype=np.float64)
+    A = np.asarray(Xa, dtype=np.float64) * inv[:, None]
+    B = np.asarray(Xb, dtype=np.float64) * inv[:, None]
+    if form == "direct":
+        r2 = np.zeros((A.shape[1], B.shape[1]))
+        for k in range(A.shape[0]):
+            diff = A[k][:, None] - B[k][None, :]
+            r2 += diff * diff
+        return np.sqrt(r2)
+    if form == "gemm":
+        sa = np.sum(A * A, axis=0)
+        sb = np.sum(B * B, axis=0)
+        r2 = sa[:, None] + sb[None, :] - 2.0 * (A.T @ B)
+        return np.sqrt(np.maximum(r2, 0.0))
+    raise ValueError(form)
+
+
+@dataclass
+class GPHyper:
+    """Hyper-parameters of one output slice AFTER the +1e-8 offsets (gaussian_process.jl:239-241)."""
+    kernel: int
+    lengthscale: np.ndarray
+    amplitude: float
+    noise_std: float
+    discrete: Optional[np.ndarray] = None
+
+
+def finite_gp_params(kernel, d, lengthscale, amplitude, noise_std, discrete=None) -> GPHyper:
+    """src/models/gaussian_process.jl:216-245 `finite_gp`: validate, then ADD 1e-8 to λ, α, σ."""
+    if isinstance(kernel, str):
+        kernel = KERNEL_NAMES[kernel]
+    lengthscale = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
+    # :227-229  @assert all(lengthscales .>= 0); amplitude >= 0; noise_std >= 0
+    assert np.all(lengthscale >= 0), "lengthscales must be >= 0"
+    assert amplitude >= 0, "amplitude must be >= 0"
+    assert noise_std >= 0, "noise_std must be >= 0"
+    # :233  @assert length(lengthscales) == size(X, 1)
+    assert lengthscale.shape[0] == d, "length(lengthscales) must equal x_dim"
+    return GPHyper(kernel, lengthscale + MIN_PARAM_VALUE, float(amplitude) + MIN_PARAM_VALUE,
+                   float(noise_std) + MIN_PARAM_VALUE,
+                   None if discrete is None else np.asarray(discrete, dtype=bool))
+
+
+def kernelmatrix(h: GPHyper, Xa: np.ndarray, Xb: Optional[np.ndarray] = None,
+                 form: str = "direct") -> np.ndarray:
+    """k(x,x') = α² κ(||(x-x')./λ||)  (gaussian_process.jl:243: `(amplitude^2) * with_lengthscale`)."""
+    Xa = discrete_round(np.asarray(Xa, dtype=np.float64), h.discrete)
+    Xb = Xa if Xb is None else discrete_round(np.asarray(Xb, dtype=np.float64), h.discrete)
+    r = scaled_distance(Xa, Xb, h.lengthscale, form)
+    return (h.amplitude ** 2) * kappa(h.kernel, r)
+
+
+# --------------------------------------------------------------------------------------
+# posterior construction   (gaussian_process.jl:199-211 -> AbstractGPs.posterior(fx, y))
+# --------------------------------------------------------------------------------------
+@dataclass
+class GPPosterior:
+    """What AbstractGPs.PosteriorGP stores: (α = C\\δ, C, x, δ) + the prior definition."""
+    h: GPHyper
+    X: np.ndarray            # d×N, one observation per column (src/types/data.jl:10-12)
+    L: np.ndarray            # lower Cholesky factor of K + σ²I
+    a: np.ndarray            # (K+σ²I)^{-1} (y - m(X))
+    delta: np.ndarray        # y - m(X)
+    logpdf: float            # log marginal likelihood of y under the FiniteGP
+
+
+def _mean_vec(mean, X: np.ndarray) -> np.ndarray:
+    """Prior mean over columns: nothing -> 0, Real -> ConstMean, Function -> CustomMean mapped
+    over columns (gaussian_process.jl:101-103,247-248); a precomputed vector is accepted as-is
+    (that is the form in which user closures cross the C ABI)."""
+    n = X.shape[1]
+    if mean is None:
+        return np.zeros(n)
+    if callable(mean):
+        return np.array([float(mean(X[:, j])) for j in range(n)], dtype=np.float64)
+    m = np.asarray(mean, dtype=np.float64)
+    if m.ndim == 0:
+        return np.full(n, float(m))
+    assert m.shape == (n,)
+    return m
+
+
+def gp_fit(X, y, kernel, lengthscale, amplitude, noise_std, mean=None, discrete=None,
+           form: str = "direct") -> GPPosterior:
+    """posterior_gp (gaussian_process.jl:199-211): K = kernelmatrix + σ²I; C = cholesky(K);
+    δ = y - m(X); a = C \\ δ.  logpdf(FiniteGP, y) = -(N log 2π + logdet C + ||C.U' \\ δ||²)/2
+    (gaussian_process.jl:279; algebra spelled out in gradient_gp.jl:325-326,403)."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    d, N = X.shape
+    assert y.shape[0] == N
+    h = finite_gp_params(kernel, d, lengthscale, amplitude, noise_std, discrete)
+    K = kernelmatrix(h, X, form=form)
+    K[np.diag_indices(N)] += h.noise_std ** 2
+    try:
+        L = sla.cholesky(K, lower=True, check_finite=False)
+    except np.linalg.LinAlgError as e:  # PosDefException in Julia
+        raise PosDefException(str(e))
+    delta = y - _mean_vec(mean, X)
+    z = sla.solve_triangular(L, delta, lower=True, check_finite=False)
+    a = sla.solve_triangular(L, z, lower=True, trans="T", check_finite=False)
+    logdet = 2.0 * float(np.sum(np.log(np.diag(L))))
+    logpdf = -0.5 * (N * _LOG2PI + logdet + float(z @ z))
+    return GPPosterior(h, X, L, a, delta, logpdf)
+
+
+def gp_data_loglike_slice(X, y, kernel, lengthscale, amplitude, noise_std, mean=None,
+                          discrete=None) -> float:
+    """gp_data_loglike_slice (gaussian_process.jl:269-280); -Inf on a non-PD matrix is what
+    `safe_data_loglike` (src/surrogate_model.jl:2-12) turns the PosDefException into."""
+    try:
+        return gp_fit(X, y, kernel, lengthscale, amplitude, noise_std, mean, discrete).logpdf
+    except PosDefException:
+        return -math.inf
+
+
+def data_loglike(X, Y, kernel, lengthscales, amplitudes, noise_stds, means=None,
+                 discrete=None) -> float:
+    """data_loglike (gaussian_process.jl:250-267): sum of per-output slices.
+    Y is P×N, lengthscales d×P, amplitudes/noise_stds length P; means: None or P entries."""
+    Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
+    lengthscales = np.asarray(lengthscales, dtype=np.float64)
+    total = 0.0
+    for i in range(Y.shape[0]):
+        m = None if means is None else means[i]
+        total += gp_data_loglike_slice(X, Y[i], kernel, lengthscales[:, i], amplitudes[i],
+                                       noise_stds[i], m, discrete)
+    return total
+
+
+# --------------------------------------------------------------------------------------
+# prediction   (gaussian_process.jl:143-194 -> AbstractGPs mean_and_var(post(X*)))
+# --------------------------------------------------------------------------------------
+def clip_var(var, threshold: float = MAX_NEG_VAR):
+    """_clip_var (gaussian_process.jl:186-194): >=0 keep; [-thr,0) -> 0; < -thr -> DomainError."""
+    v = np.asarray(var, dtype=np.float64)
+    bad = v < -threshold
+    if np.any(bad):
+        first = float(v.reshape(-1)[np.argmax(bad.reshape(-1))])
+        raise DomainError(
+            f"The posterior GP predicted variance {first} but only values above -{threshold} are tolerated.")
+    out = np.where(v >= 0.0, v, 0.0)
+    return float(out) if np.ndim(var) == 0 else out
+
+
+def gp_mean_and_var(post: GPPosterior, Xs, mean_s=None, clip: bool = True, form: str = "direct"):
+    """mean_and_var(post, X::Matrix) (gaussian_process.jl:174-178):
+    μ = m(X*) + K*ᵀ a ;  V = C.U' \\ K* ;  σ² = k(x*,x*) - Σ_i V_ij² + 1e-18 ; then _clip_var."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    if Xs.ndim == 1:
+        Xs = Xs[:, None]
+    Ks = kernelmatrix(post.h, post.X, Xs, form=form)            # N×M
+    mu = _mean_vec(mean_s, Xs) + Ks.T @ post.a
+    V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
+    kss = (post.h.amplitude ** 2) * kappa(post.h.kernel, np.zeros(Xs.shape[1]))
+    var = kss - np.sum(V * V, axis=0) + PREDICT_JITTER
+    if clip:
+        var = clip_var(var)
+    return mu, var
+
+
+def gp_mean_and_cov(post: GPPosterior, Xs, mean_s=None):
+    """mean_and_cov (gaussian_process.jl:180-184): Σ = K** - VᵀV (+1e-18 I), diagonal clipped."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    Ks = kernelmatrix(post.h, post.X, Xs)
+    mu = _mean_vec(mean_s, Xs) + Ks.T @ post.a
+    V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
+    Kss = kernelmatrix(post.h, Xs)
+    S = Kss - V.T @ V + PREDICT_JITTER * np.eye(Xs.shape[1])
+    S[np.diag_indices_from(S)] = clip_var(np.diag(S))
+    return mu, S
+
+
+def model_mean_and_var(posts: Sequence[GPPosterior], Xs, means_s=None):
+    """DefaultModelPosterior fan-out over outputs (src/posterior.jl:67-72): rows = outputs -> P×M."""
+    mus, vars_ = [], []
+    for i, p in enumerate(posts):
+        m, v = gp_mean_and_var(p, Xs, None if means_s is None else means_s[i])
+        mus.append(m)
+        vars_.append(v)
+    return np.vstack(mus), np.vstack(vars_)
+
+
+def average_mean(sample_posts: Sequence[Sequence[GPPosterior]], Xs):
+    """average_mean (src/posterior.jl:177-179): arithmetic mean over BI samples of mean(post, X)."""
+    acc = None
+    for posts in sample_posts:
+        mu, _ = model_mean_and_var(posts, Xs)
+        acc = mu if acc is None else acc + mu
+    return acc / len(sample_posts)
+
+
+# --------------------------------------------------------------------------------------
+# Expected improvement  (src/acquisitions/expected_improvement.jl)
+# --------------------------------------------------------------------------------------
+def normcdf(z):
+    """Distributions.cdf(Normal(), z) = StatsFuns.normcdf(z) = erfc(-z/√2)/2."""
+    return 0.5 * erfc(-np.asarray(z, dtype=np.float64) / math.sqrt(2.0))
+
+
+def normpdf(z):
+    """Distributions.pdf(Normal(), z) = exp(-z²/2)/√(2π)."""
+    z = np.asarray(z, dtype=np.float64)
+    return np.exp(-0.5 * z * z) / math.sqrt(2.0 * math.pi)
+
+
+def is_feasible(y, y_max) -> bool:
+    """src/utils/utils.jl:33  all(y .<= y_max)."""
+    return bool(np.all(np.asarray(y) <= np.asarray(y_max)))
+
+
+def best_so_far(fit_coefs, Y, y_max):
+    """best_so_far (expected_improvement.jl:134-140), LinFitness (src/types/fitness.jl):
+    max fitness over FEASIBLE raw data columns; None ("nothing") if Y empty or none feasible."""
+    Y = np.asarray(Y, dtype=np.float64)
+    if Y.size == 0:
+        return None
+    Y = np.atleast_2d(Y)
+    c = np.asarray(fit_coefs, dtype=np.float64)
+    best = None
+    for j in range(Y.shape[1]):
+        if is_feasible(Y[:, j], y_max):
+            f = float(c @ Y[:, j])
+            best = f if best is None or f > best else best
+    return best
+
+
+def expected_improvement_lin(fit_coefs, mu, var, best_yet: float):
+    """expected_improvement(::LinFitness) (expected_improvement.jl:93-101), vectorised over
+    candidates: mu, var are P×M.  IEEE semantics when σf == 0 (diff/0 = ±Inf) are preserved."""
+    c = np.asarray(fit_coefs, dtype=np.float64)
+    mu = np.atleast_2d(np.asarray(mu, dtype=np.float64).T).T
+    var = np.atleast_2d(np.asarray(var, dtype=np.float64).T).T
+    muf = c @ mu
+    sf = np.sqrt((c * c) @ var)
+    diff = muf - best_yet
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = diff / sf
+        ei = diff * normcdf(z) + sf * normpdf(z)
+    return np.where((diff == 0.0) & (sf == 0.0), 0.0, ei)
+
+
+def _normcdf_musigma(mu, sigma, x):
+    """StatsFuns.normcdf(μ, σ, x) as used by cdf(Normal(μ, σ), x): z = (x-μ)/σ, except that
+    for σ == 0 and x == μ the z-value is +Inf (cdf = 1).  Restated from the public StatsFuns
+    source (not in /root/reference)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = (x - mu) / sigma
+    z = np.where((sigma == 0.0) & (x == mu), np.inf, z)
+    return normcdf(z)
+
+
+def feas_prob(mu, var, y_max):
+    """feas_prob (expected_improvement.jl:113-114): Π_i cdf(Normal(μ_i, √σ²_i), y_max_i);
+    constraints === nothing -> 1.  Entries y_max_i = Inf are the `Infinity` singleton whose cdf
+    is hard-wired to 1 (src/utils/inf.jl:5-15, src/types/problem.jl:71-73)."""
+    mu = np.atleast_2d(np.asarray(mu, dtype=np.float64).T).T
+    var = np.atleast_2d(np.asarray(var, dtype=np.float64).T).T
+    if y_max is None:
+        return np.ones(mu.shape[1])
+    y_max = np.asarray(y_max, dtype=np.float64)
+    fp = np.ones(mu.shape[1])
+    for i in range(mu.shape[0]):
+        if np.isinf(y_max[i]) and y_max[i] > 0:
+            continue
+        fp = fp * _normcdf_musigma(mu[i], np.sqrt(var[i]), y_max[i])
+    return fp
+
+
+def in_bounds(Xs, lb, ub):
+    """in_bounds (src/types/domain.jl:73-78), vectorised over columns."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    lb = np.asarray(lb, dtype=np.float64)[:, None]
+    ub = np.asarray(ub, dtype=np.float64)[:, None]
+    return ~(np.any(Xs < lb, axis=0) | np.any(Xs > ub, axis=0))
+
+
+def ei_acquisition(posts_or_samples, Xs, fit_coefs, y_max, best_yet, valid_mask=None,
+                   means_s=None, constrained: Optional[bool] = None):
+    """construct_ei, all four single-posterior variants + the BI average
+    (expected_improvement.jl:68-90) wrapped by make_safe(acq, domain) (:58-65).
+
+    posts_or_samples: list of P GPPosterior (one per output), or list over S samples of such lists.
+    y_max: length-P vector (Inf allowed) or None for `constraints === nothing`.
+    best_yet: float or None ("nothing": no feasible observation yet).
+    valid_mask: bool[M], False -> acq = 0.0 (outside bounds / violated cons, evaluated by caller).
+    """
+    if len(posts_or_samples) and isinstance(posts_or_samples[0], GPPosterior):
+        samples = [posts_or_samples]
+    else:
+        samples = list(posts_or_samples)
+    Xs = np.asarray(Xs, dtype=np.float64)
+    M = Xs.shape[1]
+    if constrained is None:
+        constrained = y_max is not None
+    acc = np.zeros(M)
+    for posts in samples:
+        if (not constrained) and best_yet is None:
+            acq = np.zeros(M)                                           # :68-70
+        else:
+            mu, var = model_mean_and_var(posts, Xs, means_s)
+            if best_yet is None:
+                acq = feas_prob(mu, var, y_max)                         # :71-73
+            elif not constrained:
+                acq = expected_improvement_lin(fit_coefs, mu, var, best_yet)   # :74-76
+            else:
+                acq = expected_improvement_lin(fit_coefs, mu, var, best_yet) * feas_prob(mu, var, y_max)  # :77-84
+        acc += acq
+    acq = acc / len(samples)                                            # :87-90
+    if valid_mask is not None:
+        acq = np.where(np.asarray(valid_mask, dtype=bool), acq, 0.0)    # :58-65
+    return acq
+
+
+def argmax_first(vals):
+    """Julia `argmax` (sampling.jl:36-39): first index of the maximum."""
+    return int(np.argmax(np.asarray(vals)))
