@@ -1,0 +1,340 @@
+"""ctypes binding of libbosship.so (include/bosship.h) — the executable twin of the Julia `ccall`
+layer described in INTEGRATION.md.  There is NO CPU fallback: if the HIP library is missing or no
+GPU is visible, compute calls raise.
+
+Array conventions follow the reference (src/types/data.jl:10-12): X is d×N with one observation
+per COLUMN.  numpy arrays are converted to Fortran order so that the memory the C ABI sees is the
+same column-major block a Julia Matrix{Float64} would hand to `ccall`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbosship.so")
+
+BOSS_OK, BOSS_E_INVALID, BOSS_E_NO_DEVICE, BOSS_E_NOT_PD, BOSS_E_NEG_VAR, BOSS_E_NOT_FITTED, BOSS_E_ALLOC = range(7)
+KERNELS = {"matern32": 0, "matern52": 1, "sqexp": 2}
+FIT_NO_SYNC = 1
+
+_c_dp = C.POINTER(C.c_double)
+_c_ucp = C.POINTER(C.c_ubyte)
+
+# name -> (restype, argtypes); must list EVERY symbol include/bosship.h declares (tests check it)
+SIGNATURES = {
+    "boss_version": (C.c_char_p, []),
+    "boss_last_error": (C.c_char_p, []),
+    "boss_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "boss_set_stream": (C.c_int, [C.c_int, C.c_void_p]),
+    "boss_device_sync": (C.c_int, [C.c_int]),
+    "boss_gp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_ucp, C.POINTER(C.c_void_p)]),
+    "boss_gp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, _c_dp, C.c_int, _c_dp]),
+    "boss_gp_sync": (C.c_int, [C.c_void_p, _c_dp]),
+    "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
+                              _c_ucp, C.POINTER(C.c_void_p), _c_dp]),
+    "boss_gp_set_y": (C.c_int, [C.c_void_p, _c_dp]),
+    "boss_gp_free": (None, [C.c_void_p]),
+    "boss_gp_get_factor": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
+    "boss_gp_loglike_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
+                                        C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
+    "boss_gp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
+    "boss_cand_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.POINTER(C.c_void_p)]),
+    "boss_cand_free": (None, [C.c_void_p]),
+    "boss_acq_ei": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, _c_dp, _c_dp, _c_dp, C.c_int,
+                              C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _c_dp]),
+    "boss_prof_enable": (C.c_int, [C.c_int, C.c_int]),
+    "boss_prof_reset": (C.c_int, [C.c_int]),
+    "boss_prof_get": (C.c_int, [C.c_int, C.c_char_p, _c_dp, C.POINTER(C.c_long)]),
+}
+
+
+class BossError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[bosship status {code}] {msg}")
+        self.code = code
+
+
+class PosDefException(BossError):
+    """LinearAlgebra.PosDefException analogue (BOSS_E_NOT_PD)."""
+
+
+class DomainError(BossError):
+    """DomainError of `_clip_var` (src/models/gaussian_process.jl:186-194) (BOSS_E_NEG_VAR)."""
+
+    bad_index: int = -1
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libbosship.so and attach prototypes.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(bosship has no CPU fallback)")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc == BOSS_OK:
+        return
+    msg = load_library().boss_last_error().decode()
+    if rc == BOSS_E_NOT_PD:
+        raise PosDefException(rc, msg)
+    if rc == BOSS_E_NEG_VAR:
+        raise DomainError(rc, msg)
+    raise BossError(rc, msg)
+
+
+def _f64(a, ndim=None):
+    a = np.asfortranarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError(f"expected a {ndim}-d array, got shape {a.shape}")
+    return a
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_c_dp)
+
+
+def _ucp(a):
+    return None if a is None else a.ctypes.data_as(_c_ucp)
+
+
+def _kernel_id(kernel) -> int:
+    return KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    load_library().boss_device_count(C.byref(n))
+    return n.value
+
+
+def set_stream(device: int, stream_ptr: Optional[int]):
+    _check(load_library().boss_set_stream(device, C.c_void_p(stream_ptr or 0)))
+
+
+def device_sync(device: int = 0):
+    _check(load_library().boss_device_sync(device))
+
+
+class GP:
+    """One output slice's posterior, resident on a GPU (boss_gp_t)."""
+
+    def __init__(self, X, y, kernel="matern52", discrete=None, device: int = 0):
+        lib = load_library()
+        X = _f64(X, 2)
+        y = _f64(np.asarray(y).reshape(-1), 1)
+        self.d, self.N = X.shape
+        if y.shape[0] != self.N:
+            raise ValueError("y must have one entry per column of X")
+        self.device = device
+        self.kernel = _kernel_id(kernel)
+        disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
+        h = C.c_void_p()
+        _check(lib.boss_gp_create(device, self.kernel, self.d, self.N, _dp(X), _dp(y), _ucp(disc), C.byref(h)))
+        self._h = h
+        self.logpdf = None
+
+    def update(self, lengthscale, amplitude, noise_std, mean_X=None, sync: bool = True) -> Optional[float]:
+        lib = load_library()
+        lam = _f64(np.asarray(lengthscale).reshape(-1), 1)
+        if lam.shape[0] != self.d:
+            # gaussian_process.jl:233 @assert length(lengthscales) == size(X, 1)
+            raise BossError(BOSS_E_INVALID, "length(lengthscales) must equal x_dim")
+        m = None if mean_X is None else _f64(np.asarray(mean_X).reshape(-1), 1)
+        if m is not None and m.shape[0] != self.N:
+            raise ValueError("mean_X must have N entries")
+        out = C.c_double(0.0)
+        rc = lib.boss_gp_update(self._h, _dp(lam), float(amplitude), float(noise_std), _dp(m),
+                                0 if sync else FIT_NO_SYNC, C.byref(out))
+        _check(rc)
+        if sync:
+            self.logpdf = out.value
+            return out.value
+        return None
+
+    def sync(self) -> float:
+        out = C.c_double(0.0)
+        _check(load_library().boss_gp_sync(self._h, C.byref(out)))
+        self.logpdf = out.value
+        return out.value
+
+    def set_y(self, y):
+        y = _f64(np.asarray(y).reshape(-1), 1)
+        _check(load_library().boss_gp_set_y(self._h, _dp(y)))
+
+    def factor(self):
+        L = np.zeros((self.N, self.N), order="F")
+        z = np.zeros(self.N)
+        _check(load_library().boss_gp_get_factor(self._h, _dp(L), _dp(z)))
+        return L, z
+
+    def predict(self, Xs, mean_Xs=None):
+        """mean_and_var(post, X::Matrix): returns (mu[M], var[M]) with _clip_var applied."""
+        Xs = _f64(Xs)
+        if Xs.ndim == 1:
+            Xs = _f64(Xs.reshape(-1, 1))
+        if Xs.shape[0] != self.d:
+            raise ValueError("candidates must be d×M")
+        M = Xs.shape[1]
+        ms = None if mean_Xs is None else _f64(np.asarray(mean_Xs).reshape(-1), 1)
+        mu = np.zeros(M)
+        var = np.zeros(M)
+        bad = C.c_long(-1)
+        rc = load_library().boss_gp_predict(self._h, M, _dp(Xs), _dp(ms), _dp(mu), _dp(var), C.byref(bad))
+        if rc == BOSS_E_NEG_VAR:
+            e = DomainError(rc, load_library().boss_last_error().decode())
+            e.bad_index = bad.value
+            raise e
+        _check(rc)
+        return mu, var
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().boss_gp_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Candidates:
+    """A resident batch of candidate points (boss_cand_t)."""
+
+    def __init__(self, Xs, device: int = 0):
+        Xs = _f64(Xs, 2)
+        self.d, self.M = Xs.shape
+        self.device = device
+        h = C.c_void_p()
+        _check(load_library().boss_cand_create(device, self.d, self.M, _dp(Xs), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().boss_cand_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fit(X, y, kernel, lengthscale, amplitude, noise_std, mean_X=None, discrete=None, device: int = 0) -> GP:
+    """posterior_gp (gaussian_process.jl:199-211) through the one-shot boss_gp_fit entry point."""
+    lib = load_library()
+    X = _f64(X, 2)
+    y = _f64(np.asarray(y).reshape(-1), 1)
+    lam = _f64(np.asarray(lengthscale).reshape(-1), 1)
+    d, N = X.shape
+    if lam.shape[0] != d:
+        raise BossError(BOSS_E_INVALID, "length(lengthscales) must equal x_dim")
+    m = None if mean_X is None else _f64(np.asarray(mean_X).reshape(-1), 1)
+    disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
+    h = C.c_void_p()
+    out = C.c_double(0.0)
+    _check(lib.boss_gp_fit(device, _kernel_id(kernel), d, N, _dp(X), _dp(y), _dp(m), _dp(lam), float(amplitude),
+                           float(noise_std), _ucp(disc), C.byref(h), C.byref(out)))
+    g = GP.__new__(GP)
+    g.d, g.N, g.device, g.kernel, g._h, g.logpdf = d, N, device, _kernel_id(kernel), h, out.value
+    return g
+
+
+def loglike_batch(X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=None, discrete=None, device: int = 0):
+    """S log marginal likelihoods on the same (X, y) slice; lengthscales is d×S.
+    Returns (ll[S], status[S]); ll = -Inf where the matrix is not PD (safe_data_loglike)."""
+    X = _f64(X, 2)
+    y = _f64(np.asarray(y).reshape(-1), 1)
+    lam = _f64(lengthscales, 2)
+    d, N = X.shape
+    S = lam.shape[1]
+    if lam.shape[0] != d:
+        raise BossError(BOSS_E_INVALID, "lengthscales must be d×S")
+    amp = _f64(np.asarray(amplitudes).reshape(-1), 1)
+    sig = _f64(np.asarray(noise_stds).reshape(-1), 1)
+    stride = 0
+    m = None
+    if mean_X is not None:
+        m = np.asarray(mean_X, dtype=np.float64)
+        if m.ndim == 2:          # S×N, row s = mean of set s  → contiguous rows
+            m = np.ascontiguousarray(m)
+            stride = N
+        else:
+            m = np.ascontiguousarray(m.reshape(-1))
+    disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
+    ll = np.zeros(S)
+    st = np.zeros(S, dtype=np.int32)
+    _check(load_library().boss_gp_loglike_batch(device, _kernel_id(kernel), d, N, _dp(X), _dp(y), _dp(m), stride,
+                                                _ucp(disc), S, _dp(lam), _dp(amp), _dp(sig), _dp(ll),
+                                                st.ctypes.data_as(C.POINTER(C.c_int))))
+    return ll, st
+
+
+def acq_ei(gps: Sequence[Sequence[GP]], cand: Candidates, fit_coefs, y_max=None, best=None, valid_mask=None,
+           mean_Xs=None, want_acq: bool = True):
+    """EI·feas over resident candidates.  gps[s][p] = output p of hyper-parameter sample s.
+    mean_Xs: None or array [S][P][M].  Returns (acq[M] or None, argmax, max)."""
+    S = len(gps)
+    P = len(gps[0])
+    arr = (C.c_void_p * (P * S))()
+    for s in range(S):
+        for p in range(P):
+            arr[p + P * s] = gps[s][p]._h
+    coefs = _f64(np.asarray(fit_coefs).reshape(-1), 1)
+    ym = None if y_max is None else _f64(np.asarray(y_max).reshape(-1), 1)
+    mask = None if valid_mask is None else np.ascontiguousarray(np.asarray(valid_mask, dtype=bool).astype(np.uint8))
+    M = cand.M
+    ms = None
+    if mean_Xs is not None:
+        a = np.asarray(mean_Xs, dtype=np.float64).reshape(S, P, M)
+        ms = np.ascontiguousarray(a.transpose(0, 2, 1))       # index p + P*(j + M*s)
+    acq = np.zeros(M) if want_acq else None
+    am = C.c_long(-1)
+    mx = C.c_double(0.0)
+    _check(load_library().boss_acq_ei(P, S, arr, cand._h, _dp(ms), _dp(coefs), _dp(ym), 0 if best is None else 1,
+                                      0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am),
+                                      C.byref(mx)))
+    return acq, am.value, mx.value
+
+
+def bench_mfma_f64(device: int = 0, iters: int = 20000) -> float:
+    out = C.c_double(0.0)
+    _check(load_library().boss_bench_mfma_f64(device, iters, C.byref(out)))
+    return out.value
+
+
+def prof_enable(device: int, on: bool):
+    _check(load_library().boss_prof_enable(device, 1 if on else 0))
+
+
+def prof_reset(device: int):
+    _check(load_library().boss_prof_reset(device))
+
+
+def prof_get(device: int, kernel_class: str):
+    ms = C.c_double(0.0)
+    n = C.c_long(0)
+    _check(load_library().boss_prof_get(device, kernel_class.encode(), C.byref(ms), C.byref(n)))
+    return ms.value, n.value

@@ -1,0 +1,882 @@
+// bosship.hip — C ABI (include/bosship.h) over the HIP kernels.  gfx950 only, no CPU fallback.
+#include "../../include/bosship.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gp_kernels.hpp"
+#include "potrf.hpp"
+
+using namespace boss;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? BOSS_E_ALLOC : BOSS_E_NO_DEVICE,                     \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// per-device context: stream, grow-only workspaces, per-kernel-class event profiling
+// ------------------------------------------------------------------------------------------
+struct Workspace {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool prof_on = false;
+    std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
+    std::vector<hipEvent_t> ev_pool;
+    Workspace vscratch, csc, pred, batchA, batchX, batchMisc;
+    void* pinned = nullptr;   // small host-pinned result area
+    std::mutex mtx;
+};
+
+static std::mutex g_ctx_mtx;
+static std::map<int, Ctx*> g_ctx;
+
+static int get_ctx(int device, Ctx** out) {
+    std::lock_guard<std::mutex> lk(g_ctx_mtx);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) {
+        *out = it->second;
+        HIPCHK(hipSetDevice(device));
+        return BOSS_OK;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BOSS_E_NO_DEVICE, "no HIP device visible (bosship has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(BOSS_E_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    Ctx* c = new Ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+    // kernels that need more than 64 KiB of dynamic LDS
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<GemmNT<4, 1, 2, 2>>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<GemmNT<4, 1, 2, 2>>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<GemmNT<2, 2, 4, 2>>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<GemmNT<2, 2, 4, 2>>::BYTES));
+    g_ctx[device] = c;
+    *out = c;
+    return BOSS_OK;
+}
+
+static int ws_reserve(Workspace& w, size_t bytes) {
+    if (w.bytes >= bytes) return BOSS_OK;
+    if (w.p) (void)hipFree(w.p);
+    w.p = nullptr;
+    w.bytes = 0;
+    HIPCHK(hipMalloc(&w.p, bytes));
+    w.bytes = bytes;
+    return BOSS_OK;
+}
+
+struct ProfScope {
+    Ctx* c;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char* name;
+    ProfScope(Ctx* ctx, const char* n) : c(ctx), name(n) {
+        if (!c->prof_on) return;
+        e0 = take();
+        e1 = take();
+        (void)hipEventRecord(e0, c->stream);
+    }
+    ~ProfScope() {
+        if (!c->prof_on) return;
+        (void)hipEventRecord(e1, c->stream);
+        c->prof[name].push_back({e0, e1});
+    }
+    hipEvent_t take() {
+        if (!c->ev_pool.empty()) {
+            hipEvent_t e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------
+struct boss_gp {
+    Ctx* ctx = nullptr;
+    int kernel = 0, d = 0, N = 0, Np = 0, nblk = 0, ld = 0;
+    double *Xraw = nullptr, *Xsc = nullptr, *y = nullptr, *mean = nullptr, *A = nullptr;
+    double *inv16 = nullptr, *Dinv = nullptr, *hyp = nullptr, *invlam = nullptr, *scal = nullptr;
+    int* info = nullptr;
+    unsigned char* discrete_dev = nullptr;     // d flags (device) or null
+    std::vector<unsigned char> discrete;
+    double amp2 = 0.0;
+    bool has_mean = false, fitted = false, pending = false, have_dinv = false;
+    double* host_res = nullptr;                // pinned: scal[2], info
+    double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
+    hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
+};
+
+struct boss_cand {
+    Ctx* ctx = nullptr;
+    int d = 0, M = 0, Mp = 0;
+    double* Craw = nullptr;                    // [d][Mp]
+};
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------
+// library
+// ------------------------------------------------------------------------------------------
+extern "C" const char* boss_version(void) { return "bosship 0.1.0 (gfx950, fp64 MFMA)"; }
+extern "C" const char* boss_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int boss_device_count(int* n_out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        if (n_out) *n_out = 0;
+        return fail(BOSS_E_NO_DEVICE, "no HIP device visible (bosship has no CPU fallback)");
+    }
+    if (n_out) *n_out = n;
+    return BOSS_OK;
+}
+
+extern "C" int boss_set_stream(int device, void* hip_stream) {
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return BOSS_OK;
+}
+
+extern "C" int boss_device_sync(int device) {
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BOSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// factorisation driver (shared by the single handle and the batched log-likelihood)
+// ------------------------------------------------------------------------------------------
+static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t bstride, double* inv16,
+                          size_t inv16_bstride, int* info) {
+    const int nblk = Np / BLK;
+    hipStream_t s = c->stream;
+    for (int k = 0; k < nblk; ++k) {
+        {
+            ProfScope ps(c, "potrf_diag");
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, batch), dim3(256), DIAG_LDS_BYTES, s, A, ld, bstride, k,
+                               inv16, inv16_bstride, info);
+        }
+        const int nrows16 = (Np - (k + 1) * BLK) / 16 + 1;   // rows below + one 16-row group of the RHS block
+        {
+            ProfScope ps(c, "potrf_trsm");
+            hipLaunchKernelGGL(potrf_trsm_kernel, dim3(nrows16, 1, batch), dim3(64), 0, s, A, ld, bstride, k, inv16,
+                               inv16_bstride);
+        }
+        const int m = nblk - 1 - k;
+        const int tiles = m * (m + 1) / 2 + m;
+        if (tiles > 0) {
+            ProfScope ps(c, "potrf_syrk");
+            hipLaunchKernelGGL(potrf_syrk_kernel, dim3(tiles, 1, batch), dim3(256), SYRK_LDS_BYTES, s, A, ld, bstride,
+                               k, m);
+        }
+    }
+}
+
+static void gram_enqueue(Ctx* c, const double* Xsc, size_t xs_bstride, int d, int N, int Np, int kern,
+                         const double* hyp, double* A, int ld, size_t bstride, int batch) {
+    ProfScope ps(c, "gram");
+    const int nt = Np / 64;
+    hipLaunchKernelGGL(gram_kernel, dim3(nt * (nt + 1) / 2, 1, batch), dim3(256), 0, c->stream, Xsc, xs_bstride, d, N,
+                       Np, kern, hyp, A, ld, bstride);
+}
+
+// ------------------------------------------------------------------------------------------
+// posterior handle
+// ------------------------------------------------------------------------------------------
+static void gp_release(boss_gp* g) {
+    if (!g) return;
+    if (g->ctx) (void)hipSetDevice(g->ctx->device);
+    void* ptrs[] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->hyp, g->invlam, g->scal, g->info, g->discrete_dev};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (g->host_res) (void)hipHostFree(g->host_res);
+    if (g->host_par) (void)hipHostFree(g->host_par);
+    if (g->par_ev) (void)hipEventDestroy(g->par_ev);
+    delete g;
+}
+
+static void pack_points(std::vector<double>& dst, const double* X, int d, int n, int ldp,
+                        const unsigned char* discrete) {
+    // X is d×n column-major (point-contiguous); dst is [d][ldp] (dimension-major), padding = 0.
+    dst.assign((size_t)d * ldp, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < d; ++k) {
+            double v = X[(size_t)j * d + k];
+            if (discrete && discrete[k]) v = std::nearbyint(v);   // Julia round(): half-to-even (kernels.jl:56-59)
+            dst[(size_t)k * ldp + j] = v;
+        }
+}
+
+extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double* X, const double* y,
+                              const unsigned char* discrete, boss_gp_t** out) {
+    if (!out) return fail(BOSS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (kernel < 0 || kernel > 2) return fail(BOSS_E_INVALID, "unknown kernel id");
+    if (d < 1 || N < 1 || !X || !y) return fail(BOSS_E_INVALID, "need d >= 1, N >= 1 and non-NULL X, y");
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    boss_gp* g = new boss_gp();
+    g->ctx = c;
+    g->kernel = kernel;
+    g->d = d;
+    g->N = N;
+    g->Np = round_up(N, BLK);
+    g->nblk = g->Np / BLK;
+    g->ld = g->Np + RHS_ROWS;
+    const size_t Np = g->Np;
+#define GALLOC(ptr, bytes)                                        \
+    do {                                                          \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));       \
+        if (e_ != hipSuccess) {                                   \
+            gp_release(g);                                        \
+            return fail(BOSS_E_ALLOC, "device allocation failed"); \
+        }                                                         \
+    } while (0)
+    GALLOC(g->Xraw, sizeof(double) * d * Np);
+    GALLOC(g->Xsc, sizeof(double) * d * Np);
+    GALLOC(g->y, sizeof(double) * Np);
+    GALLOC(g->mean, sizeof(double) * Np);
+    GALLOC(g->A, sizeof(double) * (size_t)g->ld * Np);
+    GALLOC(g->inv16, sizeof(double) * g->nblk * 8 * 256);
+    GALLOC(g->Dinv, sizeof(double) * g->nblk * BLK * BLK);
+    GALLOC(g->hyp, sizeof(double) * 2);
+    GALLOC(g->invlam, sizeof(double) * d);
+    GALLOC(g->scal, sizeof(double) * 2);
+    GALLOC(g->info, sizeof(int));
+    if (hipHostMalloc((void**)&g->host_res, 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&g->host_par, sizeof(double) * (d + 2), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&g->par_ev, hipEventDisableTiming) != hipSuccess) {
+        gp_release(g);
+        return fail(BOSS_E_ALLOC, "pinned allocation failed");
+    }
+    if (discrete) {
+        g->discrete.assign(discrete, discrete + d);
+        bool any = false;
+        for (int k = 0; k < d; ++k) any |= discrete[k] != 0;
+        if (any) {
+            GALLOC(g->discrete_dev, d);
+            (void)hipMemcpy(g->discrete_dev, discrete, d, hipMemcpyHostToDevice);
+        } else {
+            g->discrete.clear();
+        }
+    }
+#undef GALLOC
+    std::vector<double> buf;
+    pack_points(buf, X, d, N, (int)Np, g->discrete.empty() ? nullptr : g->discrete.data());
+    HIPCHK(hipMemcpyAsync(g->Xraw, buf.data(), sizeof(double) * d * Np, hipMemcpyHostToDevice, c->stream));
+    std::vector<double> yb(Np, 0.0);
+    std::copy(y, y + N, yb.begin());
+    HIPCHK(hipMemcpyAsync(g->y, yb.data(), sizeof(double) * Np, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(g->mean, 0, sizeof(double) * Np, c->stream));
+    HIPCHK(hipMemsetAsync(g->A, 0, sizeof(double) * (size_t)g->ld * Np, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope
+    *out = g;
+    return BOSS_OK;
+}
+
+extern "C" int boss_gp_set_y(boss_gp_t* g, const double* y) {
+    if (!g || !y) return fail(BOSS_E_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(g->ctx->device));
+    HIPCHK(hipMemcpyAsync(g->y, y, sizeof(double) * g->N, hipMemcpyHostToDevice, g->ctx->stream));
+    HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    g->fitted = false;
+    return BOSS_OK;
+}
+
+static int validate_hyper(int d, const double* lam, double amp, double sig) {
+    // gaussian_process.jl:227-229: negative values signal an error (zero is lifted to 1e-8)
+    if (!lam) return fail(BOSS_E_INVALID, "lengthscale is NULL");
+    for (int k = 0; k < d; ++k)
+        if (!(lam[k] >= 0.0)) return fail(BOSS_E_INVALID, "lengthscales must be >= 0");
+    if (!(amp >= 0.0)) return fail(BOSS_E_INVALID, "amplitude must be >= 0");
+    if (!(sig >= 0.0)) return fail(BOSS_E_INVALID, "noise_std must be >= 0");
+    return BOSS_OK;
+}
+
+static int gp_finish(boss_gp* g, double* logpdf_out) {
+    Ctx* c = g->ctx;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    g->pending = false;
+    const double logdet = g->host_res[0], zz = g->host_res[1];
+    int info;
+    std::memcpy(&info, &g->host_res[2], sizeof(int));
+    if (info != 0 || !std::isfinite(logdet) || !std::isfinite(zz)) {
+        g->fitted = false;
+        if (logpdf_out) *logpdf_out = -std::numeric_limits<double>::infinity();
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "matrix is not positive definite (pivot %d failed) — PosDefException", info);
+        return fail(BOSS_E_NOT_PD, msg);
+    }
+    g->fitted = true;
+    if (logpdf_out) *logpdf_out = -0.5 * (g->N * 1.8378770664093453 + logdet + zz);
+    return BOSS_OK;
+}
+
+extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double amplitude, double noise_std,
+                              const double* mean_X, int flags, double* logpdf_out) {
+    if (!g) return fail(BOSS_E_INVALID, "gp is NULL");
+    int rc = validate_hyper(g->d, lengthscale, amplitude, noise_std);
+    if (rc) return rc;
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    g->fitted = false;
+    g->have_dinv = false;
+    // +1e-8 on every parameter (gaussian_process.jl:239-241)
+    HIPCHK(hipEventSynchronize(g->par_ev));   // previous update's staging copies have been consumed
+    double* invlam = g->host_par;
+    double* hyp = g->host_par + g->d;
+    for (int k = 0; k < g->d; ++k) invlam[k] = 1.0 / (lengthscale[k] + MIN_PARAM_VALUE);
+    const double amp = amplitude + MIN_PARAM_VALUE, sig = noise_std + MIN_PARAM_VALUE;
+    hyp[0] = amp * amp;
+    hyp[1] = sig * sig;
+    g->amp2 = hyp[0];
+    HIPCHK(hipMemcpyAsync(g->invlam, invlam, sizeof(double) * g->d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->hyp, hyp, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(g->par_ev, s));
+    if (mean_X) {
+        HIPCHK(hipMemcpyAsync(g->mean, mean_X, sizeof(double) * g->N, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));      // caller's (pageable) mean buffer may be reused on return
+        g->has_mean = true;
+    } else if (g->has_mean) {
+        HIPCHK(hipMemsetAsync(g->mean, 0, sizeof(double) * g->Np, s));
+        g->has_mean = false;
+    }
+    HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
+    {
+        ProfScope ps(c, "prep");
+        hipLaunchKernelGGL(scale_points_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc,
+                           (size_t)0, g->invlam, g->d, g->Np);
+        hipLaunchKernelGGL(rhs_rows_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0,
+                           g->N, g->Np, g->y, g->mean, (size_t)0);
+    }
+    gram_enqueue(c, g->Xsc, 0, g->d, g->N, g->Np, g->kernel, g->hyp, g->A, g->ld, 0, 1);
+    potrf_enqueue(c, g->A, g->ld, g->Np, 1, 0, g->inv16, 0, g->info);
+    {
+        ProfScope ps(c, "logdet");
+        hipLaunchKernelGGL(potrf_logdet_kernel, dim3(1, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0, g->N, g->Np,
+                           g->scal);
+    }
+    HIPCHK(hipMemcpyAsync(g->host_res, g->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&g->host_res[2], g->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipGetLastError());
+    g->pending = true;
+    if (flags & BOSS_FIT_NO_SYNC) return BOSS_OK;
+    return gp_finish(g, logpdf_out);
+}
+
+extern "C" int boss_gp_sync(boss_gp_t* g, double* logpdf_out) {
+    if (!g) return fail(BOSS_E_INVALID, "gp is NULL");
+    HIPCHK(hipSetDevice(g->ctx->device));
+    if (!g->pending) {
+        if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "no update pending and handle is not fitted");
+        if (logpdf_out) *logpdf_out = -0.5 * (g->N * 1.8378770664093453 + g->host_res[0] + g->host_res[1]);
+        return BOSS_OK;
+    }
+    return gp_finish(g, logpdf_out);
+}
+
+extern "C" int boss_gp_fit(int device, int kernel, int d, int N, const double* X, const double* y,
+                           const double* mean_X, const double* lengthscale, double amplitude, double noise_std,
+                           const unsigned char* discrete, boss_gp_t** out, double* logpdf_out) {
+    if (!out) return fail(BOSS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = validate_hyper(d, lengthscale, amplitude, noise_std);
+    if (rc) return rc;
+    boss_gp_t* g = nullptr;
+    rc = boss_gp_create(device, kernel, d, N, X, y, discrete, &g);
+    if (rc) return rc;
+    rc = boss_gp_update(g, lengthscale, amplitude, noise_std, mean_X, BOSS_FIT_DEFAULT, logpdf_out);
+    if (rc) {
+        std::string keep = g_last_error;
+        boss_gp_free(g);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = g;
+    return BOSS_OK;
+}
+
+extern "C" void boss_gp_free(boss_gp_t* g) {
+    if (!g) return;
+    if (g->ctx) {
+        (void)hipSetDevice(g->ctx->device);
+        (void)hipStreamSynchronize(g->ctx->stream);
+    }
+    gp_release(g);
+}
+
+extern "C" int boss_gp_get_factor(const boss_gp_t* g, double* L_out, double* z_out) {
+    if (!g) return fail(BOSS_E_INVALID, "gp is NULL");
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    HIPCHK(hipSetDevice(g->ctx->device));
+    HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    const int N = g->N;
+    if (L_out) {
+        HIPCHK(hipMemcpy2D(L_out, sizeof(double) * N, g->A, sizeof(double) * g->ld, sizeof(double) * N, N,
+                           hipMemcpyDeviceToHost));
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < j; ++i) L_out[(size_t)j * N + i] = 0.0;
+    }
+    if (z_out) {
+        HIPCHK(hipMemcpy2D(z_out, sizeof(double), g->A + g->Np, sizeof(double) * g->ld, sizeof(double), N,
+                           hipMemcpyDeviceToHost));
+    }
+    return BOSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// batched log-likelihood
+// ------------------------------------------------------------------------------------------
+extern "C" int boss_gp_loglike_batch(int device, int kernel, int d, int N, const double* X, const double* y,
+                                     const double* mean_X, int mean_stride, const unsigned char* discrete, int S,
+                                     const double* lengthscales, const double* amplitudes, const double* noise_stds,
+                                     double* ll_out, int* status_out) {
+    if (kernel < 0 || kernel > 2) return fail(BOSS_E_INVALID, "unknown kernel id");
+    if (d < 1 || N < 1 || S < 0 || !X || !y || !ll_out) return fail(BOSS_E_INVALID, "bad arguments");
+    if (S == 0) return BOSS_OK;
+    if (!lengthscales || !amplitudes || !noise_stds) return fail(BOSS_E_INVALID, "NULL hyper-parameter array");
+    if (mean_X && mean_stride != 0 && mean_stride != N) return fail(BOSS_E_INVALID, "mean_stride must be 0 or N");
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const int Np = round_up(N, BLK), nblk = Np / BLK, ld = Np + RHS_ROWS;
+    const size_t bstride = (size_t)ld * Np;
+    // chunk the batch so the matrices stay below ~12 GiB
+    size_t per = bstride * sizeof(double);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, ((size_t)12 << 30) / per));
+    const size_t xs_bstride = (size_t)d * Np;
+    rc = ws_reserve(c->batchA, per * chunk);
+    if (rc) return rc;
+    rc = ws_reserve(c->batchX, sizeof(double) * (xs_bstride * (chunk + 1) + (size_t)Np * (chunk + 1)));
+    if (rc) return rc;
+    const size_t inv16_b = (size_t)nblk * 8 * 256;
+    rc = ws_reserve(c->batchMisc, sizeof(double) * ((size_t)chunk * (inv16_b + 2 + 2 + d)) + sizeof(int) * chunk + 64);
+    if (rc) return rc;
+    double* A = (double*)c->batchA.p;
+    double* Xraw = (double*)c->batchX.p;
+    double* Xsc = Xraw + xs_bstride;
+    double* ydev = Xsc + xs_bstride * chunk;
+    double* meandev = ydev + Np;                       // chunk × Np (or Np when shared)
+    double* inv16 = (double*)c->batchMisc.p;
+    double* hyp = inv16 + inv16_b * chunk;
+    double* scal = hyp + 2 * (size_t)chunk;
+    double* invlam = scal + 2 * (size_t)chunk;
+    int* info = (int*)(invlam + (size_t)d * chunk);
+
+    std::vector<double> buf;
+    pack_points(buf, X, d, N, Np, discrete);
+    HIPCHK(hipMemcpy(Xraw, buf.data(), sizeof(double) * xs_bstride, hipMemcpyHostToDevice));
+    std::vector<double> yb(Np, 0.0);
+    std::copy(y, y + N, yb.begin());
+    HIPCHK(hipMemcpy(ydev, yb.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
+
+    std::vector<double> h_invlam((size_t)d * chunk), h_hyp(2 * (size_t)chunk), h_scal(2 * (size_t)chunk), h_mean;
+    std::vector<int> h_info(chunk), valid(chunk);
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+        const int nb = std::min(chunk, S - s0);
+        for (int b = 0; b < nb; ++b) {
+            const double* lam = lengthscales + (size_t)(s0 + b) * d;
+            bool ok = amplitudes[s0 + b] >= 0.0 && noise_stds[s0 + b] >= 0.0;
+            for (int k = 0; k < d; ++k) ok = ok && lam[k] >= 0.0;
+            valid[b] = ok;
+            const double amp = (ok ? amplitudes[s0 + b] : 1.0) + MIN_PARAM_VALUE;
+            const double sig = (ok ? noise_stds[s0 + b] : 1.0) + MIN_PARAM_VALUE;
+            for (int k = 0; k < d; ++k) h_invlam[(size_t)b * d + k] = 1.0 / ((ok ? lam[k] : 1.0) + MIN_PARAM_VALUE);
+            h_hyp[2 * b] = amp * amp;
+            h_hyp[2 * b + 1] = sig * sig;
+        }
+        HIPCHK(hipMemcpy(invlam, h_invlam.data(), sizeof(double) * d * nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(hyp, h_hyp.data(), sizeof(double) * 2 * nb, hipMemcpyHostToDevice));
+        size_t mean_b = 0;
+        const double* mean_arg = nullptr;
+        if (mean_X) {
+            if (mean_stride == 0) {
+                h_mean.assign(Np, 0.0);
+                std::copy(mean_X, mean_X + N, h_mean.begin());
+                HIPCHK(hipMemcpy(meandev, h_mean.data(), sizeof(double) * Np, hipMemcpyHostToDevice));
+            } else {
+                h_mean.assign((size_t)Np * nb, 0.0);
+                for (int b = 0; b < nb; ++b)
+                    std::copy(mean_X + (size_t)(s0 + b) * N, mean_X + (size_t)(s0 + b + 1) * N, h_mean.begin() + (size_t)b * Np);
+                HIPCHK(hipMemcpy(meandev, h_mean.data(), sizeof(double) * Np * nb, hipMemcpyHostToDevice));
+                mean_b = Np;
+            }
+            mean_arg = meandev;
+        }
+        HIPCHK(hipMemsetAsync(info, 0, sizeof(int) * nb, s));
+        HIPCHK(hipMemsetAsync(A, 0, per * nb, s));
+        {
+            ProfScope ps(c, "prep");
+            hipLaunchKernelGGL(scale_points_kernel, dim3((Np + 255) / 256, 1, nb), dim3(256), 0, s, Xraw, Xsc, xs_bstride,
+                               invlam, d, Np);
+            hipLaunchKernelGGL(rhs_rows_kernel, dim3((Np + 255) / 256, 1, nb), dim3(256), 0, s, A, ld, bstride, N, Np,
+                               ydev, mean_arg, mean_b);
+        }
+        gram_enqueue(c, Xsc, xs_bstride, d, N, Np, kernel, hyp, A, ld, bstride, nb);
+        potrf_enqueue(c, A, ld, Np, nb, bstride, inv16, inv16_b, info);
+        {
+            ProfScope ps(c, "logdet");
+            hipLaunchKernelGGL(potrf_logdet_kernel, dim3(1, 1, nb), dim3(256), 0, s, A, ld, bstride, N, Np, scal);
+        }
+        HIPCHK(hipMemcpyAsync(h_scal.data(), scal, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h_info.data(), info, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        for (int b = 0; b < nb; ++b) {
+            const double logdet = h_scal[2 * b], zz = h_scal[2 * b + 1];
+            int st = BOSS_OK;
+            double ll;
+            if (!valid[b]) {
+                st = BOSS_E_INVALID;
+                ll = -std::numeric_limits<double>::infinity();
+            } else if (h_info[b] != 0 || !std::isfinite(logdet) || !std::isfinite(zz)) {
+                st = BOSS_E_NOT_PD;
+                ll = -std::numeric_limits<double>::infinity();   // safe_data_loglike: exception → -Inf
+            } else {
+                ll = -0.5 * (N * 1.8378770664093453 + logdet + zz);
+            }
+            ll_out[s0 + b] = ll;
+            if (status_out) status_out[s0 + b] = st;
+        }
+    }
+    return BOSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// candidates + prediction
+// ------------------------------------------------------------------------------------------
+extern "C" int boss_cand_create(int device, int d, int M, const double* Xs, boss_cand_t** out) {
+    if (!out) return fail(BOSS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (d < 1 || M < 1 || !Xs) return fail(BOSS_E_INVALID, "need d >= 1, M >= 1 and non-NULL Xs");
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    boss_cand* cd = new boss_cand();
+    cd->ctx = c;
+    cd->d = d;
+    cd->M = M;
+    cd->Mp = round_up(M, 64);
+    if (hipMalloc((void**)&cd->Craw, sizeof(double) * d * cd->Mp) != hipSuccess) {
+        delete cd;
+        return fail(BOSS_E_ALLOC, "device allocation failed");
+    }
+    std::vector<double> buf;
+    pack_points(buf, Xs, d, M, cd->Mp, nullptr);
+    HIPCHK(hipMemcpy(cd->Craw, buf.data(), sizeof(double) * d * cd->Mp, hipMemcpyHostToDevice));
+    *out = cd;
+    return BOSS_OK;
+}
+
+extern "C" void boss_cand_free(boss_cand_t* cd) {
+    if (!cd) return;
+    if (cd->ctx) {
+        (void)hipSetDevice(cd->ctx->device);
+        (void)hipStreamSynchronize(cd->ctx->stream);
+    }
+    if (cd->Craw) (void)hipFree(cd->Craw);
+    delete cd;
+}
+
+// scaled (and, for DiscreteKernel dims, rounded) candidates for one GP
+__global__ void scale_cand_kernel(const double* __restrict__ Craw, double* __restrict__ Csc, const double* __restrict__ invlam,
+                                  const unsigned char* __restrict__ discrete, int d, int Mp) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Mp) return;
+    for (int k = 0; k < d; ++k) {
+        double v = Craw[(size_t)k * Mp + j];
+        if (discrete && discrete[k]) v = rint(v);
+        Csc[(size_t)k * Mp + j] = v * invlam[k];
+    }
+}
+
+// enqueue μ/σ² (unclipped) of one posterior at resident candidates into device arrays mu, var (length ≥ M)
+static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_dev, double* mu, double* var) {
+    Ctx* c = g->ctx;
+    hipStream_t s = c->stream;
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    if (cd->ctx != c) return fail(BOSS_E_INVALID, "candidates and posterior live on different devices");
+    if (cd->d != g->d) return fail(BOSS_E_INVALID, "candidate dimension differs from the model's x_dim");
+    if (!g->have_dinv) {
+        ProfScope ps(c, "dinv");
+        hipLaunchKernelGGL(potrf_dinv_kernel, dim3(8, g->nblk, 1), dim3(64), 0, s, g->A, g->ld, (size_t)0, g->inv16,
+                           (size_t)0, g->Dinv, (size_t)0);
+        g->have_dinv = true;
+    }
+    const int Mp = cd->Mp;
+    const int BN = (cd->M >= 64 * 256) ? 64 : 32;
+    const int tiles = (cd->M + BN - 1) / BN;
+    int rc = ws_reserve(c->csc, sizeof(double) * (size_t)g->d * Mp);
+    if (rc) return rc;
+    rc = ws_reserve(c->vscratch, sizeof(double) * (size_t)tiles * BN * g->Np);
+    if (rc) return rc;
+    rc = ws_reserve(c->pred, sizeof(double) * 2 * (size_t)Mp);
+    if (rc) return rc;
+    double* Csc = (double*)c->csc.p;
+    double* ss = (double*)c->pred.p;
+    double* mz = ss + Mp;
+    hipLaunchKernelGGL(scale_cand_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, cd->Craw, Csc, g->invlam,
+                       g->discrete_dev, g->d, Mp);
+    {
+        ProfScope ps(c, "predict");
+        if (BN == 32) {
+            typedef GemmNT<4, 1, 2, 2> G;
+            hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(256), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
+                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz);
+        } else {
+            typedef GemmNT<2, 2, 4, 2> G;
+            hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(256), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
+                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz);
+        }
+    }
+    hipLaunchKernelGGL(predict_finalize_kernel, dim3((cd->M + 255) / 256), dim3(256), 0, s, ss, mz, mean_s_dev, g->amp2,
+                       cd->M, mu, var);
+    HIPCHK(hipGetLastError());
+    return BOSS_OK;
+}
+
+extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const double* mean_Xs, double* mu, double* var,
+                               long* bad_index) {
+    if (!g || !Xs || !mu || !var) return fail(BOSS_E_INVALID, "NULL argument");
+    if (M < 1) return fail(BOSS_E_INVALID, "M must be >= 1");
+    if (bad_index) *bad_index = -1;
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    boss_cand_t* cd = nullptr;
+    int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
+    if (rc) return rc;
+    double* dev = nullptr;   // mu | var | mean | bad
+    if (hipMalloc((void**)&dev, sizeof(double) * (3 * (size_t)M + 2)) != hipSuccess) {
+        boss_cand_free(cd);
+        return fail(BOSS_E_ALLOC, "device allocation failed");
+    }
+    double *dmu = dev, *dvar = dev + M, *dmean = dev + 2 * (size_t)M;
+    unsigned long long* dbad = (unsigned long long*)(dev + 3 * (size_t)M);
+    hipStream_t s = c->stream;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(dev);
+        boss_cand_free(cd);
+    };
+    if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * M, hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(dbad, 0xff, sizeof(unsigned long long), s);
+    rc = predict_enqueue(g, cd, mean_Xs ? dmean : nullptr, dmu, dvar);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    hipLaunchKernelGGL(clip_var_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dvar, M, dbad);
+    unsigned long long bad = 0;
+    (void)hipMemcpyAsync(mu, dmu, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(var, dvar, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (bad != ~0ULL) {
+        if (bad_index) *bad_index = (long)bad;
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "The posterior GP predicted variance %g but only values above -1e-08 are tolerated. (DomainError)", var[bad]);
+        return fail(BOSS_E_NEG_VAR, msg);
+    }
+    return BOSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// acquisition
+// ------------------------------------------------------------------------------------------
+extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_t* cand, const double* mean_Xs,
+                           const double* fit_coefs, const double* y_max, int has_best, double best,
+                           const unsigned char* valid_mask, double* acq_out, long* argmax_out, double* max_out) {
+    if (P < 1 || S < 1 || !gps || !cand || !fit_coefs) return fail(BOSS_E_INVALID, "bad arguments");
+    Ctx* c = cand->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < P * S; ++i) {
+        if (!gps[i]) return fail(BOSS_E_INVALID, "NULL posterior handle");
+        if (gps[i]->ctx != c) return fail(BOSS_E_INVALID, "all handles and candidates must live on one device");
+        if (!gps[i]->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    }
+    hipStream_t s = c->stream;
+    const int M = cand->M;
+    // device scratch: mu[P][M] | var[P][M] | acq[M] | mean[P][M] | coefs[P] | ymax[P] | out val | out idx | mask
+    const size_t nd = (size_t)3 * P * M + M + 2 * P + 4;
+    double* dev = nullptr;
+    if (hipMalloc((void**)&dev, sizeof(double) * nd + M) != hipSuccess) return fail(BOSS_E_ALLOC, "device allocation failed");
+    double* dmu = dev;
+    double* dvar = dmu + (size_t)P * M;
+    double* dacq = dvar + (size_t)P * M;
+    double* dmean = dacq + M;
+    double* dcoef = dmean + (size_t)P * M;
+    double* dymax = dcoef + P;
+    double* dval = dymax + P;
+    long* didx = (long*)(dval + 1);
+    unsigned char* dmask = (unsigned char*)(dev + nd);
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(dev);
+    };
+    (void)hipMemcpyAsync(dcoef, fit_coefs, sizeof(double) * P, hipMemcpyHostToDevice, s);
+    if (y_max) (void)hipMemcpyAsync(dymax, y_max, sizeof(double) * P, hipMemcpyHostToDevice, s);
+    if (valid_mask) (void)hipMemcpyAsync(dmask, valid_mask, M, hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(dacq, 0, sizeof(double) * M, s);
+    const int mode = (has_best ? 1 : 0) | (y_max ? 2 : 0);
+    std::vector<double> hmean;
+    for (int sm = 0; sm < S; ++sm) {
+        if (mode != 0) {
+            if (mean_Xs) {
+                // caller layout p + P*(j + M*s)  →  device [p][j]
+                hmean.resize((size_t)P * M);
+                for (int j = 0; j < M; ++j)
+                    for (int p = 0; p < P; ++p) hmean[(size_t)p * M + j] = mean_Xs[p + (size_t)P * (j + (size_t)M * sm)];
+                (void)hipMemcpyAsync(dmean, hmean.data(), sizeof(double) * P * M, hipMemcpyHostToDevice, s);
+                (void)hipStreamSynchronize(s);
+            }
+            for (int p = 0; p < P; ++p) {
+                int rc = predict_enqueue(gps[p + (size_t)P * sm], cand, mean_Xs ? dmean + (size_t)p * M : nullptr,
+                                         dmu + (size_t)p * M, dvar + (size_t)p * M);
+                if (rc) {
+                    cleanup();
+                    return rc;
+                }
+            }
+            ProfScope ps(c, "ei");
+            hipLaunchKernelGGL(ei_accumulate_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dmu, dvar, M, P, M, dcoef,
+                               y_max ? dymax : nullptr, mode, best, dacq);
+        }
+    }
+    {
+        ProfScope ps(c, "argmax");
+        hipLaunchKernelGGL(acq_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dacq, M, 1.0 / S,
+                           valid_mask ? dmask : nullptr);
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, s, dacq, M, dval, didx);
+    }
+    double hval = 0.0;
+    long hidx = -1;
+    (void)hipMemcpyAsync(&hval, dval, sizeof(double), hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&hidx, didx, sizeof(long), hipMemcpyDeviceToHost, s);
+    if (acq_out) (void)hipMemcpyAsync(acq_out, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    hipError_t e2 = hipGetLastError();
+    cleanup();
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e2));
+    if (argmax_out) *argmax_out = hidx;
+    if (max_out) *max_out = hval;
+    return BOSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement helpers
+// ------------------------------------------------------------------------------------------
+extern "C" int boss_bench_mfma_f64(int device, int iters, double* tflops_out) {
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int blocks = prop.multiProcessorCount;   // one 4-wave workgroup per CU = one wave per SIMD
+    double* sink;
+    HIPCHK(hipMalloc((void**)&sink, 8));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(256), 0, c->stream, iters / 8 + 1, sink);   // warm-up
+    HIPCHK(hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(256), 0, c->stream, iters, sink);
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * 4.0 * (double)iters * 16.0 * 2048.0;
+    if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return BOSS_OK;
+}
+
+extern "C" int boss_prof_enable(int device, int on) {
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    c->prof_on = on != 0;
+    return BOSS_OK;
+}
+
+extern "C" int boss_prof_reset(int device) {
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& kv : c->prof)
+        for (auto& pr : kv.second) {
+            c->ev_pool.push_back(pr.first);
+            c->ev_pool.push_back(pr.second);
+        }
+    c->prof.clear();
+    return BOSS_OK;
+}
+
+extern "C" int boss_prof_get(int device, const char* kernel_class, double* ms_total, long* launches) {
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (!kernel_class) return fail(BOSS_E_INVALID, "kernel_class is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    long n = 0;
+    auto it = c->prof.find(kernel_class);
+    if (it != c->prof.end()) {
+        for (auto& pr : it->second) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) tot += ms;
+            ++n;
+        }
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = n;
+    return BOSS_OK;
+}

@@ -1,0 +1,66 @@
+// common.hpp — shared device helpers for the bosship HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace boss {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int BLK = 128;          // block size of the blocked Cholesky / triangular solves
+constexpr int RHS_ROWS = 128;     // extra row block carrying (y-m)^T through the factorisation
+constexpr int KERN_MATERN32 = 0, KERN_MATERN52 = 1, KERN_SQEXP = 2;
+constexpr double MIN_PARAM_VALUE = 1e-8;   // src/models/gaussian_process.jl:5
+constexpr double MAX_NEG_VAR = 1e-8;       // src/models/gaussian_process.jl:13
+constexpr double PREDICT_JITTER = 1e-18;   // AbstractGPs default Σy of post(X*)
+
+// v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) B(4x16) + C.
+// lane l holds A[l&15][l>>4], B[l>>4][l&15]; result reg i of lane l is D[(l>>4)+4i][l&15]
+// (/opt/skills/guides/cdna_hip_programming.md §3, f64 fragment layout).
+__device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(p) to ~1 ulp: v_rsq_f64 seed + one cubically convergent correction.
+__device__ __forceinline__ double rsqrt_refined(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    double t = p * y;
+    double e = __builtin_fma(-t, y, 1.0);
+    double c = __builtin_fma(0.375, e, 0.5);
+    y = __builtin_fma(y * e, c, y);
+    // second (cheap) polish step guards the seed's worst case
+    t = p * y;
+    e = __builtin_fma(-t, y, 1.0);
+    y = __builtin_fma(y * e, 0.5, y);
+    return y;
+}
+
+// Radial profile of the base kernel on the SQUARED scaled distance.
+// KernelFunctions.jl Matern32Kernel / Matern52Kernel / SqExponentialKernel.
+__device__ __forceinline__ double kappa_r2(int kern, double r2) {
+    if (kern == KERN_SQEXP) return exp(-0.5 * r2);
+    double r = sqrt(r2);
+    if (kern == KERN_MATERN32) {
+        double s = 1.7320508075688772 * r;
+        return (1.0 + s) * exp(-s);
+    }
+    double s = 2.23606797749979 * r;
+    return (1.0 + s + s * s / 3.0) * exp(-s);
+}
+
+__device__ __forceinline__ double normcdf_dev(double z) {   // StatsFuns.normcdf = erfc(-z/√2)/2
+    return 0.5 * erfc(-z * 0.7071067811865476);
+}
+__device__ __forceinline__ double normpdf_dev(double z) {   // exp(-z²/2)/√(2π)
+    return exp(-0.5 * z * z) * 0.3989422804014327;
+}
+
+}  // namespace boss

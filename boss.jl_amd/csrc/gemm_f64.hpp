@@ -1,0 +1,177 @@
+// gemm_f64.hpp — fp64 MFMA tile core: C(BM×BN) = Σ_k A(r,k)·B(c,k)   ("NT": both operands
+// are column-major with the contraction index as the COLUMN index: A(r,k) = A[r + k*lda],
+// B(c,k) = B[c + k*ldb]).  256 threads = 4 waves arranged WR×WC; each wave owns TM×TN
+// 16×16 MFMA tiles.  Operands are staged global → registers → LDS (double-buffered, KB=16
+// deep), fragments are read back with conflict-free ds_read_b64 (row stride padded by 16
+// doubles = 32 banks, see MI355X_MICROARCH.md §LDS).
+//
+// Accumulator orientation ("transposed trick"): the B fragment is fed as the MFMA's A
+// operand and vice versa, so result register i of lane l is
+//     C(row = m*16 + (l&15), col = n*16 + (l>>4) + 4*i)      (within the wave's sub-tile)
+// i.e. consecutive lanes hold consecutive ROWS of a column-major C: global stores/loads of C
+// are 128-byte contiguous per 16 lanes.
+#pragma once
+#include "common.hpp"
+
+namespace boss {
+
+template <int WR_, int WC_, int TM_, int TN_>
+struct GemmNT {
+    static constexpr int WR = WR_, WC = WC_, TM = TM_, TN = TN_;
+    static_assert(WR * WC == 4, "4 waves per workgroup");
+    static constexpr int BM = WR * TM * 16, BN = WC * TN * 16, KB = 16;
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile dims must be multiples of 32");
+    static constexpr int SA = BM + 16, SB = BN + 16;          // LDS row strides (doubles)
+    static constexpr int STAGE = KB * (SA + SB);              // doubles per pipeline stage
+    static constexpr int LDS_DOUBLES = 2 * STAGE;
+    static constexpr int NA = BM / 32, NB = BN / 32;          // 16-byte chunks / thread / stage
+
+    struct Stage {
+        v2d a[NA];
+        v2d b[NB];
+    };
+
+    __device__ static __forceinline__ void gload(Stage& s, const double* __restrict__ A, int lda,
+                                                 const double* __restrict__ B, int ldb, int k0, int tid) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            int q = tid + 256 * p;
+            int rp = q % (BM / 2), kk = q / (BM / 2);
+            s.a[p] = *reinterpret_cast<const v2d*>(A + (size_t)(k0 + kk) * lda + 2 * rp);
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            int q = tid + 256 * p;
+            int cp = q % (BN / 2), kk = q / (BN / 2);
+            s.b[p] = *reinterpret_cast<const v2d*>(B + (size_t)(k0 + kk) * ldb + 2 * cp);
+        }
+    }
+
+    __device__ static __forceinline__ void sstore(const Stage& s, double* __restrict__ buf, int tid) {
+        double* As = buf;
+        double* Bs = buf + KB * SA;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            int q = tid + 256 * p;
+            int rp = q % (BM / 2), kk = q / (BM / 2);
+            *reinterpret_cast<v2d*>(As + kk * SA + 2 * rp) = s.a[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            int q = tid + 256 * p;
+            int cp = q % (BN / 2), kk = q / (BN / 2);
+            *reinterpret_cast<v2d*>(Bs + kk * SB + 2 * cp) = s.b[p];
+        }
+    }
+
+    // 4 k-substeps of 4 on one staged KB=16 slab.
+    __device__ static __forceinline__ void compute(const double* __restrict__ buf, v4d (&acc)[TM][TN],
+                                                   int wr, int wc, int lane) {
+        const double* As = buf + wr * (TM * 16) + (lane & 15);
+        const double* Bs = buf + KB * SA + wc * (TN * 16) + (lane & 15);
+        const int kq = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kk = 4 * s + kq;
+            double af[TM], bf[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) af[m] = As[kk * SA + m * 16];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) bf[n] = Bs[kk * SB + n * 16];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[m][n] = mfma_f64(bf[n], af[m], acc[m][n]);
+        }
+    }
+
+    // acc += A(:,0:K)·B(:,0:K)^T.  K must be a multiple of 16 (K == 0 is a no-op).
+    // Every thread of the workgroup must call this (it contains barriers).
+    __device__ static __forceinline__ void run(const double* __restrict__ A, int lda,
+                                               const double* __restrict__ B, int ldb, int K,
+                                               v4d (&acc)[TM][TN], double* __restrict__ lds) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wr = wave / WC, wc = wave % WC;
+        const int KT = K / KB;
+        if (KT == 0) return;
+        Stage st;
+        gload(st, A, lda, B, ldb, 0, tid);
+        __syncthreads();                       // previous users of `lds` are done
+        sstore(st, lds, tid);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = (kt + 1 < KT);
+            if (more) gload(st, A, lda, B, ldb, (kt + 1) * KB, tid);
+            compute(lds + (kt & 1) * STAGE, acc, wr, wc, lane);
+            if (more) {
+                sstore(st, lds + ((kt + 1) & 1) * STAGE, tid);
+                __syncthreads();
+            }
+        }
+    }
+
+    // Same, but the B operand is already resident in LDS as Bl[k*ldbl + c] (k = 0..K-1,
+    // c = 0..BN-1, ldbl ≡ 16 mod 32 keeps fragment reads conflict-free); only A is staged.
+    __device__ static __forceinline__ void run_Blds(const double* __restrict__ A, int lda,
+                                                    const double* __restrict__ Bl, int ldbl, int K,
+                                                    v4d (&acc)[TM][TN], double* __restrict__ lds) {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wr = wave / WC, wc = wave % WC;
+        const int KT = K / KB;
+        if (KT == 0) return;
+        constexpr int ASTAGE = KB * SA;
+        v2d a[NA];
+        auto ga = [&](int k0) {
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {
+                int q = tid + 256 * p;
+                int rp = q % (BM / 2), kk = q / (BM / 2);
+                a[p] = *reinterpret_cast<const v2d*>(A + (size_t)(k0 + kk) * lda + 2 * rp);
+            }
+        };
+        auto sa = [&](double* buf) {
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {
+                int q = tid + 256 * p;
+                int rp = q % (BM / 2), kk = q / (BM / 2);
+                *reinterpret_cast<v2d*>(buf + kk * SA + 2 * rp) = a[p];
+            }
+        };
+        ga(0);
+        __syncthreads();
+        sa(lds);
+        __syncthreads();
+        const int kq = lane >> 4;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = (kt + 1 < KT);
+            if (more) ga((kt + 1) * KB);
+            const double* As = lds + (kt & 1) * ASTAGE + wr * (TM * 16) + (lane & 15);
+            const double* Bs = Bl + (size_t)(kt * KB) * ldbl + wc * (TN * 16) + (lane & 15);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kk = 4 * s + kq;
+                double af[TM], bf[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m) af[m] = As[kk * SA + m * 16];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) bf[n] = Bs[kk * ldbl + n * 16];
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[m][n] = mfma_f64(bf[n], af[m], acc[m][n]);
+            }
+            if (more) {
+                sa(lds + ((kt + 1) & 1) * ASTAGE);
+                __syncthreads();
+            }
+        }
+    }
+
+    // element coordinates of accumulator register (m, n, i) of this thread inside the BM×BN tile
+    __device__ static __forceinline__ int row_of(int wr, int m, int lane) { return wr * (TM * 16) + m * 16 + (lane & 15); }
+    __device__ static __forceinline__ int col_of(int wc, int n, int i, int lane) { return wc * (TN * 16) + n * 16 + (lane >> 4) + 4 * i; }
+};
+
+}  // namespace boss

@@ -1,0 +1,347 @@
+// gp_kernels.hpp — Gram build, fused prediction (K* tile → blocked trsm → Σv², v·z), EI epilogue, arg-max.
+#pragma once
+#include "gemm_f64.hpp"
+
+namespace boss {
+
+// ------------------------------------------------------------------------------------------
+// Layout helpers.  Points are stored dimension-major, point-contiguous: P[k*ldp + j] is
+// coordinate k of point j (so that 16 consecutive lanes read 128 contiguous bytes).
+// ------------------------------------------------------------------------------------------
+
+// Xsc[b][k][j] = Xraw[k][j] * invlam[b][k]      (ARDTransform(1 ./ λ), gaussian_process.jl:243)
+__global__ void scale_points_kernel(const double* __restrict__ Xraw, double* __restrict__ Xsc, size_t xs_bstride,
+                                    const double* __restrict__ invlam, int d, int ldp) {
+    const int b = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldp) return;
+    for (int k = 0; k < d; ++k) Xsc[(size_t)b * xs_bstride + (size_t)k * ldp + j] = Xraw[(size_t)k * ldp + j] * invlam[b * d + k];
+}
+
+// RHS row block: row Np = (y - m)^T for j < N, everything else in rows Np..Np+31 zero.
+__global__ void rhs_rows_kernel(double* __restrict__ Abase, int ld, size_t bstride, int N, int Np,
+                                const double* __restrict__ y, const double* __restrict__ mean, size_t mean_bstride) {
+    const int b = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Np) return;
+    double* col = Abase + (size_t)b * bstride + (size_t)j * ld + Np;
+    double m = mean ? mean[(size_t)b * mean_bstride + j] : 0.0;
+    col[0] = (j < N) ? (y[j] - m) : 0.0;
+#pragma unroll 1
+    for (int r = 1; r < 32; ++r) col[r] = 0.0;
+}
+
+// K1 gram_build: lower 64×64 tiles of K = α² κ(r) + σ² I  (padding rows/cols = identity).
+// hyp[b] = {α², σ²}.
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xsc, size_t xs_bstride, int d, int N,
+                                                   int Np, int kern, const double* __restrict__ hyp,
+                                                   double* __restrict__ Abase, int ld, size_t bstride) {
+    __shared__ double xj[16][64];
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const double* X = Xsc + (size_t)b * xs_bstride;
+    const double amp2 = hyp[2 * b], noise2 = hyp[2 * b + 1];
+    const int r = tid & 63, cg = tid >> 6;
+    const int i = bi * 64 + r;
+    double r2[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r2[c] = 0.0;
+    for (int k0 = 0; k0 < d; k0 += 16) {
+        const int kc = (d - k0 < 16) ? (d - k0) : 16;
+        __syncthreads();
+        for (int idx = tid; idx < kc * 64; idx += 256) xj[idx >> 6][idx & 63] = X[(size_t)(k0 + (idx >> 6)) * Np + bj * 64 + (idx & 63)];
+        __syncthreads();
+        for (int kk = 0; kk < kc; ++kk) {
+            const double xi = X[(size_t)(k0 + kk) * Np + i];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double diff = xi - xj[kk][cg * 16 + c];
+                r2[c] = __builtin_fma(diff, diff, r2[c]);
+            }
+        }
+    }
+    double* A = Abase + (size_t)b * bstride;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = bj * 64 + cg * 16 + c;
+        if (i < j) continue;
+        double v;
+        if (i < N && j < N) v = amp2 * kappa_r2(kern, r2[c]) + ((i == j) ? noise2 : 0.0);
+        else v = (i == j) ? 1.0 : 0.0;
+        A[(size_t)j * ld + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4-K7 fused prediction.  One workgroup owns BN candidates and walks the row blocks of L:
+//     R_i = K*_i − Σ_{j<i} L_ij V_j          (MFMA GEMM, V_j re-read from its own scratch slab)
+//     V_i = Dinv_i · R_i                      (MFMA GEMM, R_i resident in LDS)
+//     ss += colsum(V_i²) ,  mz += V_i^T z_i
+// which is the blocked form of  V = C.U' \ K*  (AbstractGPs var(post(X*))), with
+// μ − m(X*) = K*^T a = V^T z  accumulated in the same pass.  K* never touches HBM.
+// ------------------------------------------------------------------------------------------
+template <class G>
+struct PredictLds {
+    static constexpr int LDR = G::BN + 16;
+    static constexpr int BYTES = (G::LDS_DOUBLES + BLK * LDR + 2 * G::WR * G::BN) * 8;
+};
+
+template <class G>
+__global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
+                                                      const double* __restrict__ Dinv,
+                                                      const double* __restrict__ Xsc,
+                                                      const double* __restrict__ Csc, int d, int Mp, int kern,
+                                                      double amp2, double* __restrict__ Vscratch,
+                                                      double* __restrict__ ss_out, double* __restrict__ mz_out) {
+    static_assert(G::BM == BLK, "row block must be 128");
+    extern __shared__ double lds[];
+    constexpr int BN = G::BN, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
+    double* Rs = lds + G::LDS_DOUBLES;
+    double* red = Rs + BLK * LDR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / G::WC, wc = wave % G::WC;
+    const int c0 = blockIdx.x * BN;
+    double* V = Vscratch + (size_t)blockIdx.x * Np * BN;
+    const int nblk = Np / BLK;
+
+    double ssp[TN][4], mzp[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ssp[n][i] = mzp[n][i] = 0.0;
+
+    for (int ib = 0; ib < nblk; ++ib) {
+        v4d acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        G::run(A + (size_t)ib * BLK, ld, V, BN, ib * BLK, acc, lds);
+
+        // K*_ib tile in the accumulator layout
+        double r2[TM][TN][4];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r2[m][n][i] = 0.0;
+        for (int kd = 0; kd < d; ++kd) {
+            double xr[TM], xc[TN][4];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) xr[m] = Xsc[(size_t)kd * Np + ib * BLK + G::row_of(wr, m, lane)];
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xc[n][i] = Csc[(size_t)kd * Mp + c0 + G::col_of(wc, n, i, lane)];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double diff = xr[m] - xc[n][i];
+                        r2[m][n][i] = __builtin_fma(diff, diff, r2[m][n][i]);
+                    }
+        }
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int row = G::row_of(wr, m, lane);
+            const bool live = (ib * BLK + row) < N;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double ks = live ? amp2 * kappa_r2(kern, r2[m][n][i]) : 0.0;
+                    Rs[row * LDR + G::col_of(wc, n, i, lane)] = ks - acc[m][n][i];
+                }
+        }
+        v4d acc2[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        G::run_Blds(Dinv + (size_t)ib * BLK * BLK, BLK, Rs, LDR, BLK, acc2, lds);
+
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int row = ib * BLK + G::row_of(wr, m, lane);
+            const double zr = A[(size_t)row * ld + Np];
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double v = acc2[m][n][i];
+                    V[(size_t)row * BN + G::col_of(wc, n, i, lane)] = v;
+                    ssp[n][i] = __builtin_fma(v, v, ssp[n][i]);
+                    mzp[n][i] = __builtin_fma(v, zr, mzp[n][i]);
+                }
+        }
+        __syncthreads();   // V_ib visible to the whole workgroup before it is re-read as a B operand
+    }
+    // reduce over the 16 row-lanes, then over the WR waves stacked along rows
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double s = ssp[n][i], z = mzp[n][i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                s += __shfl_xor(s, off);
+                z += __shfl_xor(z, off);
+            }
+            if ((lane & 15) == 0) {
+                const int col = G::col_of(wc, n, i, lane);
+                red[wr * BN + col] = s;
+                red[G::WR * BN + wr * BN + col] = z;
+            }
+        }
+    __syncthreads();
+    if (tid < BN) {
+        double s = 0.0, z = 0.0;
+#pragma unroll
+        for (int w = 0; w < G::WR; ++w) {
+            s += red[w * BN + tid];
+            z += red[G::WR * BN + w * BN + tid];
+        }
+        ss_out[c0 + tid] = s;
+        mz_out[c0 + tid] = z;
+    }
+}
+
+// μ = m(x*) + V^T z ;  σ² = k(x*,x*) − Σ V² + 1e-18   (unclipped; clipping is the consumer's job)
+__global__ void predict_finalize_kernel(const double* __restrict__ ss, const double* __restrict__ mz,
+                                        const double* __restrict__ mean_s, double amp2, int M,
+                                        double* __restrict__ mu, double* __restrict__ var) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    mu[j] = (mean_s ? mean_s[j] : 0.0) + mz[j];
+    var[j] = amp2 - ss[j] + PREDICT_JITTER;
+}
+
+// first index with var < -MAX_NEG_VAR  (DomainError of _clip_var); bad[0] initialised to LONG_MAX
+__global__ void clip_var_kernel(double* __restrict__ var, int M, unsigned long long* __restrict__ bad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double v = var[j];
+    if (v >= 0.0) return;
+    if (v >= -MAX_NEG_VAR) var[j] = 0.0;
+    else atomicMin(bad, (unsigned long long)j);
+}
+
+// ------------------------------------------------------------------------------------------
+// K8 EI·feas epilogue for one hyper-parameter sample: acq_sum[j] += acq_s(x_j)
+// (expected_improvement.jl:68-101,113-114).  mu/var are P×M (row p at p*ldm).
+// mode bit0: has best_yet, bit1: constrained.  A candidate whose variance is < -1e-8 in any
+// output is poisoned with -Inf (SafeFunction semantics, src/acquisition.jl:21-25).
+// ------------------------------------------------------------------------------------------
+__global__ void ei_accumulate_kernel(const double* __restrict__ mu, const double* __restrict__ var, int ldm, int P,
+                                     int M, const double* __restrict__ coefs, const double* __restrict__ ymax,
+                                     int mode, double best, double* __restrict__ acq_sum) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    if (mode == 0) return;                                  // construct_ei(…, nothing, …, nothing): acq ≡ 0
+    double muf = 0.0, vf = 0.0, fp = 1.0;
+    bool poison = false;
+    for (int p = 0; p < P; ++p) {
+        double m = mu[(size_t)p * ldm + j], v = var[(size_t)p * ldm + j];
+        if (v < 0.0) {
+            if (v >= -MAX_NEG_VAR) v = 0.0;
+            else poison = true;
+        }
+        muf = __builtin_fma(coefs[p], m, muf);
+        vf = __builtin_fma(coefs[p] * coefs[p], v, vf);
+        if ((mode & 2) && !(isinf(ymax[p]) && ymax[p] > 0.0)) {
+            double s = sqrt(v);
+            double z = (s == 0.0 && ymax[p] == m) ? INFINITY : (ymax[p] - m) / s;
+            fp *= normcdf_dev(z);
+        }
+    }
+    double acq;
+    if (mode & 1) {
+        double sf = sqrt(vf);
+        double diff = muf - best;
+        double ei;
+        if (diff == 0.0 && sf == 0.0) ei = 0.0;
+        else {
+            double z = diff / sf;
+            ei = diff * normcdf_dev(z) + sf * normpdf_dev(z);
+        }
+        acq = (mode & 2) ? ei * fp : ei;
+    } else {
+        acq = fp;
+    }
+    if (poison) acq = -INFINITY;
+    acq_sum[j] += acq;
+}
+
+// acq = acq_sum / S, masked to 0 outside the domain (make_safe, expected_improvement.jl:58-65)
+__global__ void acq_finalize_kernel(double* __restrict__ acq, int M, double inv_s,
+                                    const unsigned char* __restrict__ mask) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double a = acq[j] * inv_s;
+    if (mask && !mask[j]) a = 0.0;
+    acq[j] = a;
+}
+
+// K9 arg-max (Julia argmax: first index of the maximum, NaN counts as the largest value).
+__device__ __forceinline__ bool better(double a, long ia, double b, long ib) {
+    const bool an = a != a, bn = b != b;
+    if (an != bn) return an;
+    if (!an && a != b) return a > b;
+    return ia < ib;
+}
+__global__ __launch_bounds__(256) void argmax_kernel(const double* __restrict__ vals, int M, double* __restrict__ out_val,
+                                                     long* __restrict__ out_idx) {
+    __shared__ double sv[256];
+    __shared__ long si[256];
+    double bv = -INFINITY;
+    long bi = 0x7fffffffffffffffL;
+    for (int j = threadIdx.x; j < M; j += 256) {
+        double v = vals[j];
+        if (bi == 0x7fffffffffffffffL || better(v, j, bv, bi)) { bv = v; bi = j; }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            double ov = sv[threadIdx.x + st];
+            long oi = si[threadIdx.x + st];
+            if (oi != 0x7fffffffffffffffL && (si[threadIdx.x] == 0x7fffffffffffffffL || better(ov, oi, sv[threadIdx.x], si[threadIdx.x]))) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_val[0] = sv[0];
+        out_idx[0] = si[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// issue-rate microbenchmark of v_mfma_f64_16x16x4_f64 (16 independent accumulators per wave)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* __restrict__ sink) {
+    v4d acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 + threadIdx.x * 1e-4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = mfma_f64(a, b, acc[t]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    if (s == 12345.678) sink[0] = s;
+}
+
+}  // namespace boss

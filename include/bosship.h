@@ -1,0 +1,156 @@
+/* bosship.h — C ABI of the MI355X-native GP-posterior + acquisition hot path for BOSS.jl.
+ *
+ * This is the drop-in boundary: the entry points are what a Julia `ccall`
+ * layer behind BOSS's SurrogateModel / ModelFitter / AcquisitionMaximizer plugin API binds
+ * (see INTEGRATION.md for the Julia stubs, and boss.jl_amd/ for the ctypes twin this pipeline
+ * can execute).  Each function cites the reference code it replaces, relative to the
+ * reference tree (soldasim/BOSS.jl v0.6.1).
+ *
+ * Conventions
+ *   - all arrays are fp64, column-major, ONE OBSERVATION PER COLUMN (src/types/data.jl:10-12):
+ *     X is d×N (x[k + d*j] = k-th coordinate of point j), candidates Xs are d×M.
+ *   - the caller owns every host buffer; the library owns device memory behind opaque handles.
+ *   - every function returns an int status (0 = BOSS_OK); no exception crosses the boundary;
+ *     boss_last_error() returns a thread-local message for the last non-zero status.
+ *   - the library is re-entrant across handles; one handle must not be used from two host
+ *     threads at once (the reference calls its closures from Threads.@threads regions:
+ *     src/utils/optim_multistart.jl:61-90, src/acquisition_maximizers/grid.jl:56-65).
+ *   - there is NO CPU fallback: without a visible gfx950 device every compute entry point
+ *     returns BOSS_E_NO_DEVICE.
+ */
+#ifndef BOSSHIP_H
+#define BOSSHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------ */
+#define BOSS_OK            0
+#define BOSS_E_INVALID     1   /* bad argument: the reference's @assert failures (gaussian_process.jl:227-233) */
+#define BOSS_E_NO_DEVICE   2   /* no HIP device / HIP runtime error */
+#define BOSS_E_NOT_PD      3   /* K + sigma^2 I not positive definite <-> LinearAlgebra.PosDefException */
+#define BOSS_E_NEG_VAR     4   /* posterior variance < -1e-8 <-> DomainError from _clip_var (gaussian_process.jl:186-194) */
+#define BOSS_E_NOT_FITTED  5   /* predict / acquisition on a handle that has no valid factorisation */
+#define BOSS_E_ALLOC       6   /* device allocation failed */
+
+/* ---- kernels: KernelFunctions.jl Matern32Kernel / Matern52Kernel (default, src/deprecated.jl:34) /
+ *      SqExponentialKernel, always as alpha^2 * kernel ∘ ARDTransform(1 ./ lambda)
+ *      (src/models/gaussian_process.jl:243) ------------------------------------------- */
+#define BOSS_K_MATERN32 0
+#define BOSS_K_MATERN52 1
+#define BOSS_K_SQEXP    2
+
+/* flags for boss_gp_update */
+#define BOSS_FIT_DEFAULT   0
+#define BOSS_FIT_NO_SYNC   1   /* enqueue only; logpdf_out is ignored, fetch later with boss_gp_sync */
+
+typedef struct boss_gp   boss_gp_t;    /* one output slice's posterior: resident X, y, L, z (GaussianProcessPosterior, gaussian_process.jl:127-131) */
+typedef struct boss_cand boss_cand_t;  /* a resident batch of candidate points (the `xs` of SamplingAM.sample, sampling.jl:43-46) */
+
+/* ---- library ---------------------------------------------------------------------- */
+const char* boss_version(void);
+const char* boss_last_error(void);
+/* number of visible HIP devices (0 and BOSS_E_NO_DEVICE when none). */
+int boss_device_count(int* n_devices_out);
+/* run all work for `device` on the caller's HIP stream (e.g. torch's current stream); NULL restores the library's own stream. */
+int boss_set_stream(int device, void* hip_stream);
+/* block until everything enqueued on the device's stream has finished. */
+int boss_device_sync(int device);
+
+/* ---- posterior construction ---------------------------------------------------------
+ * Replaces: posterior_gp / finite_gp / AbstractGPs.posterior (src/models/gaussian_process.jl:199-248)
+ *           and logpdf(FiniteGP, y) (gp_data_loglike_slice, :269-280).
+ *
+ * boss_gp_create uploads the data of ONE output slice and keeps it resident:
+ *   X        d×N, y N (row `slice` of ExperimentData.Y),
+ *   discrete d flags or NULL — DiscreteKernel: flagged dims are rounded (half-to-even) in both
+ *            kernel arguments (src/models/utils/kernels.jl:56-59).
+ * boss_gp_update (re)builds the posterior for given hyper-parameters on the resident data:
+ *   lengthscale d values, amplitude, noise_std: all must be >= 0 (else BOSS_E_INVALID); 1e-8 is
+ *            ADDED to each (MIN_PARAM_VALUE, gaussian_process.jl:5,239-241);
+ *   mean_X   N prior-mean values m(x_j) or NULL for the zero mean — user closures / the
+ *            Semiparametric parametric mean (src/models/semiparametric.jl:79-84) are evaluated
+ *            by the caller;
+ *   logpdf_out  log marginal likelihood -(N log 2pi + logdet C + ||C.U'\(y-m)||^2)/2, may be NULL.
+ * On a non-PD matrix returns BOSS_E_NOT_PD, *logpdf_out = -Inf (what safe_data_loglike yields,
+ * src/surrogate_model.jl:2-12) and the handle is left unfitted. */
+int boss_gp_create(int device, int kernel, int d, int N, const double* X, const double* y,
+                   const unsigned char* discrete, boss_gp_t** out);
+int boss_gp_update(boss_gp_t* gp, const double* lengthscale, double amplitude, double noise_std,
+                   const double* mean_X, int flags, double* logpdf_out);
+/* wait for an update enqueued with BOSS_FIT_NO_SYNC; returns its status and logpdf. */
+int boss_gp_sync(boss_gp_t* gp, double* logpdf_out);
+/* one-shot convenience = create + update (the `boss_gp_fit` of SURVEY §8b). */
+int boss_gp_fit(int device, int kernel, int d, int N, const double* X, const double* y,
+                const double* mean_X, const double* lengthscale, double amplitude, double noise_std,
+                const unsigned char* discrete, boss_gp_t** out, double* logpdf_out);
+/* append-free refresh of the observations of a resident handle (same N): y only. */
+int boss_gp_set_y(boss_gp_t* gp, const double* y);
+void boss_gp_free(boss_gp_t* gp);
+
+/* introspection for parity tests: lower Cholesky factor L (N×N column-major, upper part zeroed)
+ * and z = L \ (y - m) (N). Either pointer may be NULL. */
+int boss_gp_get_factor(const boss_gp_t* gp, double* L_out, double* z_out);
+
+/* ---- batched log-likelihood -----------------------------------------------------------
+ * Replaces: the `loglike.(samples)` loop of SamplingMAP (src/model_fitters/sampling.jl:59-78) and the
+ * per-sample likelihood calls of OptimizationMAP / TuringBI (src/model_fitters/optimization.jl:153-160,
+ * ext/TuringExt.jl:78-86) for S hyper-parameter sets on the same (X, y) slice.
+ *   lengthscales d×S (column s = set s), amplitudes S, noise_stds S,
+ *   mean_X NULL, or N values shared by all sets (mean_stride = 0), or S×N with mean_stride = N.
+ *   ll_out S (‑Inf where not PD), status_out S (BOSS_OK / BOSS_E_NOT_PD / BOSS_E_INVALID) or NULL. */
+int boss_gp_loglike_batch(int device, int kernel, int d, int N, const double* X, const double* y,
+                          const double* mean_X, int mean_stride, const unsigned char* discrete,
+                          int S, const double* lengthscales, const double* amplitudes,
+                          const double* noise_stds, double* ll_out, int* status_out);
+
+/* ---- prediction -------------------------------------------------------------------------
+ * Replaces: mean_and_var(post, X::Matrix) (gaussian_process.jl:174-178) =
+ *   mu = m(X*) + K*' a ; V = C.U' \ K* ; var = k(x*,x*) - sum_i V_ij^2 + 1e-18 ; _clip_var.
+ *   Xs d×M, mean_Xs M values m(x*_j) or NULL; mu, var: M each.
+ * Returns BOSS_E_NEG_VAR and the first offending index in *bad_index (else -1) when a variance is
+ * below -1e-8 (DomainError); mu/var are still written (var unclipped at the offending entries). */
+int boss_gp_predict(boss_gp_t* gp, int M, const double* Xs, const double* mean_Xs,
+                    double* mu, double* var, long* bad_index);
+
+/* resident candidates (one upload, many acquisition passes / many posteriors) */
+int boss_cand_create(int device, int d, int M, const double* Xs, boss_cand_t** out);
+void boss_cand_free(boss_cand_t* cand);
+
+/* ---- acquisition ------------------------------------------------------------------------
+ * Replaces: the `vals = acq.(eachcol(xs)); argmax(vals)` loop of SamplingAM / GridAM
+ * (src/acquisition_maximizers/sampling.jl:43-46,36-39; grid.jl:52-65) with acq built by
+ * construct_acquisition(::ExpectedImprovement) (src/acquisitions/expected_improvement.jl:49-90):
+ *   gps       P×S handles, gps[p + P*s] = output p of hyper-parameter sample s (S = 1 for MAP);
+ *             the acquisition is averaged over s (:87-90);
+ *   mean_Xs   NULL or P×M×S prior means at the candidates, index p + P*(j + M*s);
+ *   fit_coefs P LinFitness coefficients (src/types/fitness.jl);
+ *   y_max     P upper constraints, +Inf allowed (-> factor 1, src/utils/inf.jl), or NULL for
+ *             `constraints === nothing`;
+ *   has_best/best  best_so_far(...) (:134-140) — has_best = 0 means `nothing`;
+ *   valid_mask M bytes or NULL: 0 -> acq = 0.0 (make_safe, :58-65: outside bounds / cons, evaluated
+ *             by the caller because `cons` is a user closure);
+ *   acq_out   M values or NULL; a candidate whose variance raises DomainError gets -Inf, as the
+ *             reference's SafeFunction wrapper does (src/acquisition.jl:21-25);
+ *   argmax_out / max_out  first index of the maximum (Julia argmax) over this batch and its value.
+ * All handles and `cand` must live on the same device. */
+int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_t* cand,
+                const double* mean_Xs, const double* fit_coefs, const double* y_max,
+                int has_best, double best, const unsigned char* valid_mask,
+                double* acq_out, long* argmax_out, double* max_out);
+
+/* ---- measurement helpers (bench.py / profiles) ------------------------------------------ */
+/* issue-rate microbenchmark of v_mfma_f64_16x16x4_f64: every SIMD of the device issues
+ * `iters` x 16 independent MFMAs; returns the achieved TFLOP/s (calibrates the fp64 MFMA peak
+ * that /opt/skills/guides/MI355X_MICROARCH.md does not list). */
+int boss_bench_mfma_f64(int device, int iters, double* tflops_out);
+/* per-kernel-class HIP-event timing: enable, run work, then read back (ms_total, launches). */
+int boss_prof_enable(int device, int on);
+int boss_prof_reset(int device);
+int boss_prof_get(int device, const char* kernel_class, double* ms_total, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOSSHIP_H */
