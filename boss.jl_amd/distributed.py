@@ -1,0 +1,81 @@
+"""One-process-per-GPU helpers (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).  The hot path shards embarrassingly (candidates / outputs /
+hyper-parameter samples) so the only exchange is a 16-byte (value, index) all-gather
+for the arg-max — RCCL has no MAXLOC, so every rank reduces the gathered pairs locally."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        return dist if dist.is_available() and dist.is_initialized() else None
+    except Exception:
+        return None
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    d = _dist()
+    if d is None:
+        return 0, 1
+    return d.get_rank(group), d.get_world_size(group)
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous balanced shard [lo, hi) of n items (first n % world ranks get one extra) —
+    the analogue of get_sample_counts (src/utils/sampling.jl:6-13)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _device_for(d, group):
+    import torch
+    backend = d.get_backend(group)
+    if backend == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def argmax_exchange(val: float, idx: int, group=None) -> Tuple[float, int]:
+    """Global arg-max of per-rank (value, GLOBAL index) pairs: larger value wins, NaN counts as
+    the largest (Julia argmax), ties go to the smaller index — identical on every rank."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return val, idx
+    import torch
+    dev = _device_for(d, group)
+    world = d.get_world_size(group)
+    mine = torch.tensor([val, float(idx)], dtype=torch.float64, device=dev)
+    out = [torch.empty(2, dtype=torch.float64, device=dev) for _ in range(world)]
+    d.all_gather(out, mine, group=group)
+    pairs = [(float(t[0]), int(t[1])) for t in out]
+    return reduce_pairs(pairs)
+
+
+def reduce_pairs(pairs):
+    best_v, best_i = pairs[0]
+    for v, i in pairs[1:]:
+        vn, bn = v != v, best_v != best_v
+        if vn != bn:
+            better = vn
+        elif not vn and v != best_v:
+            better = v > best_v
+        else:
+            better = i < best_i
+        if better:
+            best_v, best_i = v, i
+    return best_v, best_i
+
+
+def allgather_concat(local: np.ndarray, group=None) -> np.ndarray:
+    """Concatenate per-rank 1-D float64 arrays (ragged shards allowed)."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return np.asarray(local, dtype=np.float64)
+    objs = [None] * d.get_world_size(group)
+    d.all_gather_object(objs, np.asarray(local, dtype=np.float64), group=group)
+    return np.concatenate(objs)

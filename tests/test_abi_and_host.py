@@ -1,0 +1,131 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/bosship.h declares
+(no compute without a GPU), argument validation, host logic of the plugin mirror, golden fixtures
+vs the oracle."""
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    entry.build()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "bosship.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(boss_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from boss_jl_amd import api
+    lib = api.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in bosship.h but not exported"
+    assert sorted(api.SIGNATURES) == syms, "ctypes SIGNATURES must cover exactly the header's entry points"
+    assert b"bosship" in lib.boss_version()
+
+
+def test_no_gpu_fails_loudly_and_validates_arguments():
+    import torch
+    from boss_jl_amd import api
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert api.device_count() == 0
+    with pytest.raises(api.BossError) as e:
+        api.GP(np.zeros((2, 3)), np.zeros(3))
+    assert e.value.code == api.BOSS_E_NO_DEVICE and "no CPU fallback" in str(e.value)
+    # argument validation happens before any device work (gaussian_process.jl:227-233 asserts)
+    with pytest.raises(api.BossError) as e:
+        api.fit(np.zeros((2, 3)), np.zeros(3), "matern52", [-1.0, 1.0], 1.0, 1.0)
+    assert e.value.code == api.BOSS_E_INVALID
+    with pytest.raises(api.BossError) as e:
+        api.fit(np.zeros((2, 3)), np.zeros(3), "matern52", [1.0], 1.0, 1.0)
+    assert e.value.code == api.BOSS_E_INVALID
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "boss.jl_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), f"{fn} must not reference the oracle"
+    for fn in os.listdir(os.path.join(pkg, "csrc")):
+        assert "oracle" not in open(os.path.join(pkg, "csrc", fn)).read()
+
+
+def test_golden_fixtures_match_oracle():
+    from oracle import gp_oracle as O
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "gp_golden.json")))
+    assert len(cases) >= 8
+    for c in cases:
+        X, y, Xs = np.array(c["X"]), np.array(c["y"]), np.array(c["Xs"])
+        post = O.gp_fit(X, y, c["kernel"], c["lengthscale"], c["amplitude"], c["noise_std"], mean=c["mean_X"],
+                        discrete=c["discrete"])
+        mu, var = O.gp_mean_and_var(post, Xs, c["mean_Xs"], clip=False)
+        assert abs(post.logpdf - c["logpdf"]) <= 1e-11 * (1 + abs(c["logpdf"]))
+        assert np.allclose(mu, c["mu"], rtol=0, atol=1e-11) and np.allclose(var, c["var"], rtol=0, atol=1e-11)
+        acq = O.ei_acquisition([post], Xs, [1.0], [np.inf], c["best"], means_s=None if c["mean_Xs"] is None else [np.array(c["mean_Xs"])])
+        assert np.allclose(acq, c["acq_ei"], rtol=0, atol=1e-12) and int(np.argmax(acq)) == c["argmax"]
+
+
+# ---------------------------------------------------------------------------- host logic
+def test_domain_and_best_so_far():
+    import boss_jl_amd as B
+    from boss_jl_amd.problem import best_so_far, in_bounds, in_domain
+    dom = B.Domain(bounds=([5., 5.], [10., 10.]))
+    X = np.array([[1., 5., 7., 10., 11.], [6., 6., 6., 6., 6.]])
+    assert in_bounds(X, dom.bounds).tolist() == [False, True, True, True, False]
+    dom2 = B.Domain(bounds=([0.], [10.]), discrete=[True], cons=lambda x: [x[0] - 2.0])
+    assert in_domain(np.array([[1., 2., 2.5, 3.]]), dom2).tolist() == [False, True, False, True]
+    # test/unit/test/acquisitions/expected_improvement.jl:165-179
+    Y = np.array([[1., 2., 3.]])
+    assert best_so_far(B.LinFitness([1.]), Y, [np.inf]) == 3.
+    assert best_so_far(B.LinFitness([2.]), Y, [np.inf]) == 6.
+    assert best_so_far(B.LinFitness([1.]), np.array([[10., 2., 3.]]), [5.]) == 3.
+    assert best_so_far(B.LinFitness([1.]), Y, [0.]) is None
+    assert best_so_far(B.LinFitness([1.]), np.zeros((1, 0)), [0.]) is None
+
+
+def test_priors_and_sampler():
+    import boss_jl_amd as B
+    m = B.HipGaussianProcess(lengthscale_priors=[B.MvLogNormal([1., 1.], [1., 1.])] * 2,
+                             amplitude_priors=[B.LogNormal()] * 2, noise_std_priors=[B.Dirac(1e-4)] * 2)
+    p = m.params_sampler()(np.random.default_rng(0))
+    assert p.lengthscales.shape == (2, 2) and p.amplitudes.shape == (2,) and np.all(p.noise_std == 1e-4)
+    ll = m.params_loglike()
+    assert math.isfinite(ll(p))
+    p.noise_std[0] = 2e-4            # off the Dirac -> -Inf  (gaussian_process.jl test :318-356)
+    assert ll(p) == -math.inf
+    from scipy import stats
+    assert abs(B.LogNormal().logpdf(1.7) - stats.lognorm(s=1.0).logpdf(1.7)) < 1e-12
+    s = p.slice(1)
+    assert s.lengthscales.shape == (2, 1)
+    from boss_jl_amd.model import join_slices
+    j = join_slices([p.slice(0), p.slice(1)])
+    assert np.array_equal(j.lengthscales, p.lengthscales)
+
+
+def test_shard_range_and_reduce_pairs():
+    from boss_jl_amd.distributed import reduce_pairs, shard_range
+    for n in (0, 1, 7, 8192, 8193):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    assert reduce_pairs([(1.0, 5), (3.0, 9), (3.0, 2)]) == (3.0, 2)          # tie -> smaller index
+    v, i = reduce_pairs([(1.0, 0), (float("nan"), 7), (5.0, 3)])
+    assert i == 7 and v != v                                                   # NaN is the largest (Julia argmax)
+    assert reduce_pairs([(-np.inf, 10), (-np.inf, 4)]) == (-np.inf, 4)

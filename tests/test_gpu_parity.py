@@ -1,0 +1,333 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs, against the committed golden fixtures, and — at BASELINE.json's full
+sizes — through size-independent properties.
+
+Stated fp64 tolerance (BASELINE.md §2 / SURVEY §8c):
+    |Δμ| <= 1e-9 (1+|μ|),  |Δσ²| <= 1e-9 α²,  |Δlogpdf| <= 1e-9 (1+|logpdf|)   for cond(K) <= 1e6,
+    condition-aware  cond(K)·N·2⁻⁵³·C  beyond that.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    entry.build()
+    from boss_jl_amd import api as a
+    a.load_library()
+    assert a.device_count() >= 1
+    return a
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import gp_oracle
+    return gp_oracle
+
+
+def make(d, N, M, seed=1, noise=0.05, scale=1.0):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, scale, (d, N))
+    y = np.sin(2 * np.pi * X / scale).sum(0) / np.sqrt(d) + noise * rng.standard_normal(N)
+    Xs = np.random.default_rng(seed + 1000).uniform(0, scale, (d, M))
+    return X, y, Xs
+
+
+def tol_for(O, post, N):
+    K = O.kernelmatrix(post.h, post.X)
+    K[np.diag_indices(N)] += post.h.noise_std ** 2
+    c = np.linalg.cond(K)
+    return max(1e-9, c * N * 2.0 ** -53 * 8), c
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+@pytest.mark.parametrize("d,N,M", [(1, 1, 1), (1, 3, 4), (2, 16, 5), (8, 127, 31), (8, 128, 32), (8, 129, 33), (3, 300, 70), (8, 1000, 257)])
+def test_fit_predict_parity(api, O, kernel, d, N, M):
+    X, y, Xs = make(d, N, M)
+    lam = np.linspace(0.3, 0.7, d)
+    post = O.gp_fit(X, y, kernel, lam, 1.2, 0.05)
+    mu_o, var_o = O.gp_mean_and_var(post, Xs, clip=False)
+    tol, _ = tol_for(O, post, N)
+    g = api.GP(X, y, kernel)
+    lp = g.update(lam, 1.2, 0.05)
+    assert abs(lp - post.logpdf) <= tol * (1 + abs(post.logpdf))
+    L, z = g.factor()
+    assert np.allclose(L, post.L, rtol=0, atol=tol * np.abs(post.L).max())
+    z_o = O.sla.solve_triangular(post.L, post.delta, lower=True)
+    assert np.allclose(z, z_o, rtol=0, atol=tol * (1 + np.abs(z_o).max()))
+    mu, var = g.predict(Xs)
+    assert np.allclose(mu, mu_o, rtol=0, atol=tol * (1 + np.abs(mu_o).max()))
+    assert np.allclose(var, O.clip_var(var_o), rtol=0, atol=tol * 1.2 ** 2)
+    # vector form == column of the matrix form (gaussian_process.jl test :121-126, atol 1e-8)
+    mu1, var1 = g.predict(Xs[:, 0])
+    assert abs(mu1[0] - mu[0]) <= 1e-12 * (1 + abs(mu[0])) and abs(var1[0] - var[0]) <= 1e-12
+    g.close()
+
+
+@pytest.mark.parametrize("noise", [1e-1, 1e-2, 1e-4])
+def test_condition_aware_tolerance_sweep(api, O, noise):
+    """σ sweep of BASELINE.md §2: the error stays inside cond(K)·N·eps as the matrix gets stiffer."""
+    X, y, Xs = make(8, 512, 64, seed=7, noise=noise)
+    lam = np.full(8, 0.5)
+    post = O.gp_fit(X, y, "matern52", lam, 1.0, noise)
+    mu_o, var_o = O.gp_mean_and_var(post, Xs, clip=False)
+    tol, cond = tol_for(O, post, 512)
+    g = api.GP(X, y, "matern52")
+    lp = g.update(lam, 1.0, noise)
+    mu, var = g.predict(Xs)
+    assert abs(lp - post.logpdf) <= tol * (1 + abs(post.logpdf))
+    assert np.allclose(mu, mu_o, rtol=0, atol=tol * (1 + np.abs(mu_o).max()))
+    assert np.allclose(var, O.clip_var(var_o), rtol=0, atol=tol)
+    g.close()
+
+
+def test_golden_fixtures(api):
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "gp_golden.json")))
+    for c in cases:
+        X, y, Xs = np.array(c["X"]), np.array(c["y"]), np.array(c["Xs"])
+        g = api.fit(X, y, c["kernel"], c["lengthscale"], c["amplitude"], c["noise_std"], c["mean_X"], c["discrete"])
+        assert abs(g.logpdf - c["logpdf"]) <= 1e-9 * (1 + abs(c["logpdf"])), c["name"]
+        L, z = g.factor()
+        assert np.allclose(np.diag(L), c["L_diag"], rtol=1e-10, atol=0), c["name"]
+        assert np.allclose(z, c["z"], rtol=0, atol=1e-8 * (1 + np.abs(c["z"]).max())), c["name"]
+        try:
+            mu, var = g.predict(Xs, c["mean_Xs"])
+        except api.DomainError:
+            assert min(c["var"]) < -1e-8
+            continue
+        assert np.allclose(mu, c["mu"], rtol=0, atol=1e-8 * (1 + np.abs(c["mu"]).max())), c["name"]
+        assert np.allclose(var, np.maximum(c["var"], 0.0), rtol=0, atol=1e-8 * c["amplitude"] ** 2), c["name"]
+        cand = api.Candidates(Xs)
+        ms = None if c["mean_Xs"] is None else np.array(c["mean_Xs"])[None, None, :]
+        acq, am, mx = api.acq_ei([[g]], cand, [1.0], [np.inf], c["best"], None, ms)
+        assert np.allclose(acq, c["acq_ei"], rtol=0, atol=1e-8), c["name"]
+        assert am == c["argmax"] or abs(acq[am] - c["acq_ei"][c["argmax"]]) <= 1e-12, c["name"]
+        g.close()
+
+
+def test_semiparametric_mean_and_discrete(api, O):
+    X, y, Xs = make(3, 150, 40, seed=3, scale=4.0)
+    lam = np.array([1.5, 2.0, 1.0])
+    disc = [False, True, False]
+    mX = 0.5 + 0.2 * X.sum(0)
+    ms = 0.5 + 0.2 * Xs.sum(0)
+    post = O.gp_fit(X, y, "matern52", lam, 0.9, 0.05, mean=mX, discrete=disc)
+    mu_o, var_o = O.gp_mean_and_var(post, Xs, ms)
+    g = api.GP(X, y, "matern52", discrete=disc)
+    lp = g.update(lam, 0.9, 0.05, mean_X=mX)
+    mu, var = g.predict(Xs, ms)
+    assert abs(lp - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf))
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-9 * (1 + np.abs(mu_o).max())) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+    # switching back to the zero mean on the same handle
+    lp0 = g.update(lam, 0.9, 0.05)
+    assert abs(lp0 - O.gp_fit(X, y, "matern52", lam, 0.9, 0.05, discrete=disc).logpdf) <= 1e-9 * (1 + abs(lp0))
+    g.close()
+
+
+def test_zero_params_get_min_param_value(api, O):
+    """gaussian_process.jl:239-241: zero λ/α/σ are lifted to 1e-8, not rejected."""
+    X = np.array([[1., 2., 3.]])
+    y = np.array([1., -1., 1.])
+    want = O.gp_fit(X, y, "matern52", [1.0], 1.0, 0.0).logpdf
+    g = api.GP(X, y, "matern52")
+    assert abs(g.update([1.0], 1.0, 0.0) - want) <= 1e-7 * (1 + abs(want))
+    for bad in ([-1.0], ):
+        with pytest.raises(api.BossError) as e:
+            g.update(bad, 1.0, 0.1)
+        assert e.value.code == api.BOSS_E_INVALID
+    with pytest.raises(api.BossError):
+        g.update([1.0], -1.0, 0.1)
+    with pytest.raises(api.BossError):
+        g.update([1.0, 1.0], 1.0, 0.1)
+    g.close()
+
+
+def test_not_positive_definite(api, O):
+    X = np.array([[1., 1., 1., 2.]])          # duplicates + ~zero noise -> singular
+    y = np.array([1., 2., 3., 4.])
+    assert O.gp_data_loglike_slice(X, y, "sqexp", [1.], 1.0, 0.0) == -np.inf
+    g = api.GP(X, y, "sqexp")
+    with pytest.raises(api.PosDefException):
+        g.update([1.], 1.0, 0.0)
+    with pytest.raises(api.BossError) as e:
+        g.predict(np.array([[1.5]]))
+    assert e.value.code == api.BOSS_E_NOT_FITTED
+    assert np.isfinite(g.update([1.], 1.0, 0.1))       # handle recovers
+    g.close()
+
+
+def test_loglike_batch(api, O):
+    X, y, _ = make(4, 200, 1, seed=11)
+    rng = np.random.default_rng(4)
+    S = 9
+    lam = np.exp(-0.7 + 0.3 * rng.standard_normal((4, S)))
+    amp = np.exp(0.3 * rng.standard_normal(S))
+    sig = np.exp(-3 + 0.3 * rng.standard_normal(S))
+    amp[3] = -1.0                                        # invalid set -> BOSS_E_INVALID, -Inf
+    ll, st = api.loglike_batch(X, y, "matern52", lam, amp, sig)
+    for s in range(S):
+        if s == 3:
+            assert st[s] == api.BOSS_E_INVALID and ll[s] == -np.inf
+            continue
+        want = O.gp_data_loglike_slice(X, y, "matern52", lam[:, s], amp[s], sig[s])
+        assert st[s] == api.BOSS_OK and abs(ll[s] - want) <= 1e-9 * (1 + abs(want))
+    # shared and per-sample prior means
+    m_shared = 0.1 * X.sum(0)
+    ll2, _ = api.loglike_batch(X, y, "sqexp", lam[:, :2], np.abs(amp[:2]), sig[:2], mean_X=m_shared)
+    m_per = np.stack([m_shared, -m_shared])
+    ll3, _ = api.loglike_batch(X, y, "sqexp", lam[:, :2], np.abs(amp[:2]), sig[:2], mean_X=m_per)
+    for s in range(2):
+        w2 = O.gp_data_loglike_slice(X, y, "sqexp", lam[:, s], abs(amp[s]), sig[s], mean=m_shared)
+        w3 = O.gp_data_loglike_slice(X, y, "sqexp", lam[:, s], abs(amp[s]), sig[s], mean=m_per[s])
+        assert abs(ll2[s] - w2) <= 1e-9 * (1 + abs(w2)) and abs(ll3[s] - w3) <= 1e-9 * (1 + abs(w3))
+    # a non-PD member does not poison its neighbours
+    Xd = np.array([[1., 1., 1., 2.]])
+    yd = np.array([1., 2., 3., 4.])
+    ll4, st4 = api.loglike_batch(Xd, yd, "sqexp", np.array([[1., 1.]]), [1., 1.], [0.0, 0.5])
+    assert st4[0] == api.BOSS_E_NOT_PD and ll4[0] == -np.inf
+    assert abs(ll4[1] - O.gp_data_loglike_slice(Xd, yd, "sqexp", [1.], 1., 0.5)) <= 1e-9
+
+
+@pytest.mark.parametrize("mode", ["none", "cons_only", "best_only", "both"])
+def test_ei_modes_multi_output_and_samples(api, O, mode):
+    """construct_ei's four variants + BI averaging over S=3 samples, P=2 outputs, masked candidates."""
+    d, N, M, P, S = 3, 120, 77, 2, 3
+    rng = np.random.default_rng(21)
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), np.cos(2 * X).sum(0) - 1.0]) + 0.05 * rng.standard_normal((P, N))
+    Xs = np.asfortranarray(rng.uniform(-0.1, 1.1, (d, M)))
+    y_max = None if mode in ("none", "best_only") else np.array([np.inf, 0.3])
+    coefs = [1.0, 0.5]
+    best = None if mode in ("none", "cons_only") else O.best_so_far(coefs, Y, [np.inf, 0.3])
+    mask = O.in_bounds(Xs, [0.] * d, [1.] * d)
+    gps, posts = [], []
+    for s in range(S):
+        lam = np.exp(-0.5 + 0.2 * rng.standard_normal((d, P)))
+        amp = np.exp(0.2 * rng.standard_normal(P))
+        gps.append([api.fit(X, Y[p], "matern52", lam[:, p], amp[p], 0.05) for p in range(P)])
+        posts.append([O.gp_fit(X, Y[p], "matern52", lam[:, p], amp[p], 0.05) for p in range(P)])
+    cand = api.Candidates(Xs)
+    acq, am, mx = api.acq_ei(gps, cand, coefs, y_max, best, mask)
+    want = O.ei_acquisition(posts, Xs, coefs, y_max, best, valid_mask=mask)
+    assert np.allclose(acq, want, rtol=0, atol=1e-10)
+    assert am == int(np.argmax(acq)) and mx == acq[am]
+    if mode == "none":
+        assert np.all(acq == 0.0)
+    assert np.all(acq[~mask] == 0.0)
+
+
+def test_ei_known_answers_through_device(api):
+    """EI / feas_prob known answers (test/unit/test/acquisitions/expected_improvement.jl:108-163)
+    pushed through the device epilogue with a nearly deterministic posterior (far from data the GP
+    reverts to its prior: μ = m(x), σ² = α²)."""
+    X = np.array([[0.0]])
+    y = np.array([0.0])
+    far = np.array([[1e6]])
+    cand = api.Candidates(far)
+
+    def acq(amp, mean_s, y_max, best):
+        g = api.fit(X, y, "sqexp", [1.0], amp, 1.0)
+        a, _, _ = api.acq_ei([[g]], cand, [1.0], y_max, best, None, np.array(mean_s, float).reshape(1, 1, 1))
+        return a[0]
+    assert acq(1.0, [0.0], None, 0.0) > 0.0                       # EI(μ=0, σ²=1, b=0) > 0
+    assert abs(acq(0.0, [1.0], None, 0.0) - 1.0) <= 1e-12         # EI(μ=1, σ²≈0, b=0) == 1
+    assert abs(acq(1.0, [-10.0], None, 0.0)) <= 1e-20             # EI(μ=-10, σ²=1) ≈ 0
+    assert abs(acq(1.0, [0.0], [0.0], None) - 0.5) <= 1e-12       # feas_prob = 0.5
+    assert acq(1.0, [0.0], [np.inf], None) == 1.0                 # Infinity -> cdf = 1
+    assert 0.99 < acq(1.0, [0.0], [3.0], None) < 1.0
+
+
+def test_argmax_first_index_on_ties(api):
+    X = np.array([[0.0]])
+    g = api.fit(X, np.array([0.0]), "sqexp", [1.0], 1.0, 1.0)
+    Xs = np.full((1, 70), 1e6)                                       # identical candidates -> identical acq
+    a, am, mx = api.acq_ei([[g]], api.Candidates(Xs), [1.0], None, 0.0)
+    assert np.all(a == a[0]) and am == 0
+    mask = np.ones(70, bool)
+    mask[:5] = False                                                 # masked -> 0.0 < EI
+    a, am, _ = api.acq_ei([[g]], api.Candidates(Xs), [1.0], None, 0.0, mask)
+    assert am == 5 and np.all(a[:5] == 0.0)
+
+
+def test_plugin_trio_reference_properties(api):
+    """The reference's own GP posterior property suite (test/unit/test/models/gaussian_process.jl:57-148)
+    and one BO iteration, driven through the host mirror of the plugin interface."""
+    import boss_jl_amd as B
+    from boss_jl_amd.bo import bo_step, estimate_parameters
+    X3 = np.array([[2., 5., 8.], [2., 5., 8.]])
+    model = B.HipGaussianProcess(lengthscale_priors=[B.MvLogNormal([1., 1.], [1., 1.])] * 2,
+                                 amplitude_priors=[B.LogNormal()] * 2, noise_std_priors=[B.Dirac(1e-4)] * 2,
+                                 mean=lambda x: [1., 1.])
+    problem = B.BossProblem(f=lambda x: x, domain=B.Domain(bounds=([0., 0.], [10., 10.])), y_max=[np.inf, 5.],
+                            acquisition=B.ExpectedImprovement(B.LinFitness([1., 0.])), model=model,
+                            data=B.ExperimentData(X3, X3.copy()))
+    fitted = estimate_parameters(problem, B.HipBatchedMAP(samples=200, seed=7))
+    assert np.isfinite(fitted.loglike)
+    post = model.model_posterior(problem.params, problem.data)
+    m = lambda x: post.mean(np.array(x, float))
+    v = lambda x: post.var(np.array(x, float))
+    for pt in ([2., 2.], [5., 5.], [8., 8.]):
+        assert np.allclose(m(pt), pt, atol=0.01)
+    assert np.all(m([1., 1.]) < 2.0) and np.all(m([4., 4.]) < 5.0)
+    assert np.allclose(m([100., 100.]), [1., 1.], atol=0.01)
+    assert np.all(v([2., 2.]) <= v([3., 3.])) and np.all(v([10., 10.]) <= v([11., 11.]))
+    Xm = np.array([[1., 2., 3.], [1., 2., 3.]])
+    mu, var = post.mean_and_var(Xm)
+    assert mu.shape == (2, 3) and var.shape == (2, 3)
+    for j in range(3):
+        muj, varj = post.mean_and_var(Xm[:, j])
+        assert np.allclose(mu[:, j], muj, atol=1e-8) and np.allclose(var[:, j], varj, atol=1e-8)
+    assert np.allclose(post.std(Xm), np.sqrt(var))
+    # one BO iteration: the maximiser returns an in-domain point and the dataset grows
+    am = B.HipBatchAM(x_prior=lambda rng: rng.uniform(0, 10, 2), samples=300, seed=3)
+    x, val = bo_step(problem, B.HipBatchedMAP(samples=50, seed=1), am)
+    assert x.shape == (2,) and np.all(x >= 0) and np.all(x <= 10) and np.isfinite(val)
+    assert problem.data.X.shape == (2, 4) and not problem.consistent
+
+
+# ------------------------------------------------------------------------------------------
+# full BASELINE size: size-independent properties
+# ------------------------------------------------------------------------------------------
+def test_full_size_properties(api, O):
+    d, N, M = 8, 4096, 8192
+    X, y, Xs = make(d, N, M, seed=1)
+    lam = np.full(d, 0.5)
+    g = api.GP(X, y, "matern52")
+    lp = g.update(lam, 1.0, 0.05)
+    L, z = g.factor()
+    h = O.finite_gp_params("matern52", d, lam, 1.0, 0.05)
+    K = O.kernelmatrix(h, X)
+    K[np.diag_indices(N)] += h.noise_std ** 2
+    # (1) L L^T reconstructs K: backward-stable Cholesky bound  ||LL^T - K|| <= c N eps ||K||
+    R = L @ L.T - K
+    assert np.abs(R).max() <= 50 * N * 2.0 ** -53 * np.abs(K).max()
+    # (2) L z = y and the log-likelihood identity
+    assert np.allclose(L @ z, y, rtol=0, atol=1e-10 * (1 + np.abs(y).max()))
+    assert abs(lp - (-0.5 * (N * np.log(2 * np.pi) + 2 * np.log(np.diag(L)).sum() + z @ z))) <= 1e-9 * (1 + abs(lp))
+    # (3) against the oracle (LAPACK) at full size
+    post = O.gp_fit(X, y, "matern52", lam, 1.0, 0.05)
+    assert abs(lp - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf))
+    # (4) acquisition over all 8192 candidates: a 512-candidate slice equals the oracle, the batch
+    #     result restricted to that slice equals the slice-only result, and arg-max is consistent
+    cand = api.Candidates(Xs)
+    b = float(y.max())
+    acq, am, mx = api.acq_ei([[g]], cand, [1.0], None, b)
+    assert am == int(np.argmax(acq)) and mx == acq[am]
+    sl = slice(1000, 1512)
+    want = O.ei_acquisition([post], Xs[:, sl], [1.0], None, b)
+    assert np.allclose(acq[sl], want, rtol=0, atol=1e-10)
+    acq_sl, _, _ = api.acq_ei([[g]], api.Candidates(Xs[:, sl]), [1.0], None, b)
+    assert np.allclose(acq_sl, acq[sl], rtol=0, atol=1e-13)
+    # (5) interpolation property: predicting AT the data recovers y to within the noise level
+    mu, var = g.predict(X[:, :256])
+    assert np.abs(mu - y[:256]).max() < 0.2 and np.all(var >= 0) and np.all(var < 0.05 ** 2 + 1e-6)
+    g.close()
