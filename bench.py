@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — the BASELINE.json metric on MI355X: GP-posterior updates/sec and acquisition-evals/sec
+at N=4096, d=8, fp64.
+
+A "step" is one pass of the hot path over one batch of synthetic input (BASELINE.json configs[1]+[2]):
+  (1) one GP posterior update  = Gram build + Cholesky of K+σ²I + z = L\\(y-m) + log-likelihood
+      on resident (X, y)  (boss_gp_update),
+  (2) one batched acquisition  = posterior mean/variance + analytic EI + arg-max over M = 8192
+      resident candidates (boss_acq_ei), followed — when N>1 ranks — by the 16-byte RCCL
+      all-gather that picks the global arg-max.
+N>1 (one process per GPU, torchrun): weak scaling — every rank owns an independent GP (a different
+output slice / hyper-parameter sample, seeded by rank) and an independent shard of 8192 candidates;
+the only collective is the arg-max exchange.
+
+Prints ONE JSON line on rank 0.  `value` = whole-job posterior updates/s; `acq_evals_per_sec` is
+the second half of the metric; `roofline` is for the dominant kernel (the fused prediction kernel);
+`cpu_baseline` times the CPU oracle (oracle/gp_oracle.py, scipy/OpenBLAS) on this host, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_OBS, D, M_CAND = 4096, 8, 8192
+FP64_MFMA_PEAK_TFLOPS = 78.6          # AMD MI355X datasheet (vector = matrix fp64); tools/mfma_probe measures 77.6
+KERNEL = "matern52"
+
+
+def problem(seed):
+    """SURVEY §8d config 2/3 inputs."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (D, N_OBS))
+    y = np.sin(2 * np.pi * X).sum(0) / np.sqrt(D) + 0.05 * rng.standard_normal(N_OBS)
+    Xs = np.random.default_rng(seed + 1).uniform(0, 1, (D, M_CAND))
+    return X, y, Xs
+
+
+def flops_update(N, d):
+    return N ** 3 / 3 + 2 * N ** 2 + N ** 2 * (3 * d + 20) / 2
+
+
+def flops_acq_eval(N, d):
+    return N ** 2 + N * (3 * d + 20) + 4 * N
+
+
+def cpu_baseline(X, y, Xs, lam):
+    """The CPU oracle on this host's cores: one posterior update (dpotrf + 2 dtrsv) and a bounded
+    sample of acquisition evaluations in the reference's call pattern (one dtrsv per candidate,
+    expected_improvement.jl:75,79) and in the best-effort batched pattern (one dtrsm)."""
+    from oracle import gp_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 6.0 and reps < 8):
+        post = O.gp_fit(X, y, KERNEL, lam, 1.0, 0.05)
+        reps += 1
+    t_upd = (time.perf_counter() - t0) / reps
+    b = float(y.max())
+    n_faithful, n_batched = 48, 2048
+    t0 = time.perf_counter()
+    for j in range(n_faithful):                                            # per-candidate vector form
+        O.ei_acquisition([post], Xs[:, j:j + 1], [1.0], None, b)
+    t_f = (time.perf_counter() - t0) / n_faithful
+    t0 = time.perf_counter()
+    O.ei_acquisition([post], Xs[:, :n_batched], [1.0], None, b)
+    t_b = (time.perf_counter() - t0) / n_batched
+    return {
+        "value": 1.0 / t_upd, "unit": "updates/s", "cores": int(threads), "kind": "port",
+        "sample": f"{reps} posterior updates at N={N_OBS}; {n_faithful} per-candidate (dtrsv) and {n_batched} batched (dtrsm) acquisition evals",
+        "acq_evals_per_sec_reference_pattern": 1.0 / t_f, "acq_evals_per_sec_batched": 1.0 / t_b,
+        "host_cpu_count": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (bosship has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    entry.build()
+    from boss_jl_amd import api
+    from boss_jl_amd import distributed as dist_util
+    dev = local_rank
+
+    X, y, Xs = problem(1 + 10 * rank)            # every rank: its own GP slice + its own candidate shard
+    lam = np.full(D, 0.5)
+    gp = api.GP(X, y, KERNEL, device=dev)
+    cand = api.Candidates(Xs, device=dev)
+    best = float(y.max())
+
+    def step(i):
+        t0 = time.perf_counter()
+        # a different noise level each step so no step can reuse the previous factorisation
+        gp.update(lam, 1.0, 0.05 + 1e-4 * (i % 7))
+        t1 = time.perf_counter()
+        _, am, mx = api.acq_ei([[gp]], cand, [1.0], None, best, want_acq=False)
+        if world > 1:
+            mx, am = dist_util.argmax_exchange(mx, am + rank * M_CAND)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, am, mx
+
+    def sync_all():
+        api.device_sync(dev)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    t_begin = time.perf_counter()
+    t_upd = t_acq = 0.0
+    for i in range(args.steps):
+        a, b, am, mx = step(i)
+        t_upd += a
+        t_acq += b
+    sync_all()
+    elapsed = time.perf_counter() - t_begin
+
+    times = torch.tensor([elapsed, t_upd, t_acq], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    elapsed, t_upd, t_acq = (float(v) for v in times.cpu())
+
+    # ---- per-kernel HIP-event timing of the dominant kernels (separate pass, events on the library's stream)
+    roof = roof_potrf = None
+    if rank == 0:
+        api.prof_enable(dev, True)
+        api.prof_reset(dev)
+        reps = 3
+        for i in range(reps):
+            step(i)
+        ms_pred, n_pred = api.prof_get(dev, "predict")
+        ms_syrk, n_syrk = api.prof_get(dev, "potrf_syrk")
+        ms_diag, n_diag = api.prof_get(dev, "potrf_diag")
+        ms_trsm, n_trsm = api.prof_get(dev, "potrf_trsm")
+        api.prof_enable(dev, False)
+        fl_pred = M_CAND * flops_acq_eval(N_OBS, D)                         # algorithmic flops per launch
+        ach = fl_pred / (ms_pred / n_pred * 1e-3) / 1e12
+        roof = {"kernel": "predict_kernel", "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": ms_pred / n_pred, "flops_per_launch": fl_pred}
+        fl_potrf = N_OBS ** 3 / 3
+        t_potrf = (ms_syrk + ms_diag + ms_trsm) / reps * 1e-3
+        ach2 = fl_potrf / t_potrf / 1e12
+        roof_potrf = {"kernel": "potrf (diag+trsm+syrk launches)", "bound": "mfma", "achieved": ach2,
+                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach2 / FP64_MFMA_PEAK_TFLOPS,
+                      "ms_per_factorisation": t_potrf * 1e3,
+                      "ms_diag": ms_diag / reps, "ms_trsm": ms_trsm / reps, "ms_syrk": ms_syrk / reps}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(X, y, Xs, lam)
+
+    if rank == 0:
+        upd_rate = world * args.steps / t_upd
+        acq_rate = world * args.steps * M_CAND / t_acq
+        out = {
+            "metric": "gp_posterior_updates_per_sec (+ acq_evals_per_sec), N=4096 d=8 fp64",
+            "value": upd_rate, "unit": "updates/s",
+            "acq_evals_per_sec": acq_rate,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_update": t_upd / args.steps * 1e3, "ms_acq_batch": t_acq / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "d=8 synthetic blackbox, GaussianProcess(Matern52) surrogate, N=4096 fp64 posterior update "
+                                   "+ ExpectedImprovement over 8192 candidates per GPU (BASELINE.json configs[1]+[2])",
+                       "N": N_OBS, "d": D, "M_per_gpu": M_CAND, "kernel": KERNEL,
+                       "parallelism": f"{world} independent GP slices + candidate shards, 16-byte RCCL arg-max all-gather"},
+            "frac_of_fp64_mfma_roofline": {"update": flops_update(N_OBS, D) * upd_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12),
+                                           "acq": flops_acq_eval(N_OBS, D) * acq_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12)},
+            "roofline": roof, "roofline_potrf": roof_potrf, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
