@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -17,6 +18,9 @@
 #include "potrf.hpp"
 
 using namespace boss;
+
+typedef GemmDirect<4, 1, 2, 2, 16> PredG32;   // 128 rows × 32 candidates per workgroup
+typedef GemmDirect<4, 1, 2, 4, 4> PredG64;   // 128 rows × 64 candidates per workgroup
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -46,6 +50,10 @@ struct Ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;          // trailing updates of the look-ahead Cholesky
+    std::vector<hipEvent_t> ev_panel, ev_rest;  // per-step dependency events (no timing)
+    hipEvent_t ev_fork = nullptr;
+    bool lookahead = true;
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -73,14 +81,31 @@ static int get_ctx(int device, Ctx** out) {
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    {
+        // Side stream for the bulk trailing updates of the look-ahead Cholesky.  Its CU mask leaves
+        // every 4th CU free so that the (short, latency-critical) panel-chain kernels on the main
+        // stream always find an idle CU instead of queueing behind 128×128 syrk workgroups.
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount;
+        const int every = getenv("BOSS_CU_RESERVE_EVERY") ? atoi(getenv("BOSS_CU_RESERVE_EVERY")) : 0;   // measured: no gain from reserving CUs
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu; ++i)
+            if (every <= 1 || (i % every) != 0) mask[i / 32] |= (1u << (i % 32));
+        if (hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        }
+    }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    c->lookahead = !(getenv("BOSS_NO_LOOKAHEAD") && atoi(getenv("BOSS_NO_LOOKAHEAD")));
     HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<GemmNT<4, 1, 2, 2>>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               PredictLds<GemmNT<4, 1, 2, 2>>::BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<GemmNT<2, 2, 4, 2>>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               PredictLds<GemmNT<2, 2, 4, 2>>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG32>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG64>::BYTES));
     g_ctx[device] = c;
     *out = c;
     return BOSS_OK;
@@ -189,11 +214,25 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
                           size_t inv16_bstride, int* info) {
     const int nblk = Np / BLK;
     hipStream_t s = c->stream;
+    // Look-ahead needs no profiling scopes (they would serialise the two streams) and >= 3 blocks.
+    const bool la = c->lookahead && !c->prof_on && nblk >= 3;
+    if (la) {
+        while ((int)c->ev_panel.size() < nblk) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+            c->ev_panel.push_back(e0);
+            c->ev_rest.push_back(e1);
+        }
+        (void)hipEventRecord(c->ev_fork, s);                 // side stream starts after everything enqueued so far
+        (void)hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);
+    }
+    int last_rest = -1;
     for (int k = 0; k < nblk; ++k) {
         {
             ProfScope ps(c, "potrf_diag");
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, batch), dim3(256), DIAG_LDS_BYTES, s, A, ld, bstride, k,
-                               inv16, inv16_bstride, info);
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, batch), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, A, ld, bstride,
+                               k, inv16, inv16_bstride, info);
         }
         const int nrows16 = (Np - (k + 1) * BLK) / 16 + 1;   // rows below + one 16-row group of the RHS block
         {
@@ -202,13 +241,31 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
                                inv16_bstride);
         }
         const int m = nblk - 1 - k;
-        const int tiles = m * (m + 1) / 2 + m;
-        if (tiles > 0) {
+        if (m == 0) break;
+        if (!la) {
             ProfScope ps(c, "potrf_syrk");
-            hipLaunchKernelGGL(potrf_syrk_kernel, dim3(tiles, 1, batch), dim3(256), SYRK_LDS_BYTES, s, A, ld, bstride,
-                               k, m);
+            hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m * (m + 1) / 2 + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
+                               k + 1, m);
+            continue;
+        }
+        // ---- look-ahead: panel chain on `s`, bulk of the trailing update on the side stream ----------
+        // the next panel's block column was last written by the side stream's update of step k-1
+        if (last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);
+        hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, k, m);
+        last_rest = -1;
+        if (m >= 2) {
+            // the bulk update is released only AFTER the column update has been dispatched, so the two
+            // do not fight for CUs; it then overlaps the next diagonal block + panel solve
+            const int m2 = m - 1;                             // block triangle beyond the next panel
+            (void)hipEventRecord(c->ev_panel[k], s);
+            (void)hipStreamWaitEvent(c->side_stream, c->ev_panel[k], 0);
+            hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m2 * (m2 + 1) / 2 + m2, 1, batch), dim3(256), 0, c->side_stream, A,
+                               ld, bstride, k, k + 2, m2);
+            (void)hipEventRecord(c->ev_rest[k], c->side_stream);
+            last_rest = k;
         }
     }
+    if (la && last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);   // join
 }
 
 static void gram_enqueue(Ctx* c, const double* Xsc, size_t xs_bstride, int d, int N, int Np, int kern,
@@ -659,16 +716,17 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     double* mz = ss + Mp;
     hipLaunchKernelGGL(scale_cand_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, cd->Craw, Csc, g->invlam,
                        g->discrete_dev, g->d, Mp);
+    const int dbg = getenv("BOSS_DBG") ? atoi(getenv("BOSS_DBG")) : 0;
     {
         ProfScope ps(c, "predict");
         if (BN == 32) {
-            typedef GemmNT<4, 1, 2, 2> G;
-            hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(256), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
-                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz);
+            typedef PredG32 G;
+            hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
+                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz, dbg);
         } else {
-            typedef GemmNT<2, 2, 4, 2> G;
-            hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(256), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
-                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz);
+            typedef PredG64 G;
+            hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
+                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz, dbg);
         }
     }
     hipLaunchKernelGGL(predict_finalize_kernel, dim3((cd->M + 255) / 256), dim3(256), 0, s, ss, mz, mean_s_dev, g->amp2,

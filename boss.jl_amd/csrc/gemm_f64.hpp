@@ -174,4 +174,117 @@ struct GemmNT {
     __device__ static __forceinline__ int col_of(int wc, int n, int i, int lane) { return wc * (TN * 16) + n * 16 + (lane >> 4) + 4 * i; }
 };
 
+// ------------------------------------------------------------------------------------------
+// GemmDirect — same contraction as GemmNT, but the MFMA fragments are streamed straight from
+// global/L2 into a D-deep register ring: no LDS, no barriers, waves drift freely.  fp64 MFMA is
+// slow relative to memory (64 cycles per 2 KFLOP), so L2 feeds it comfortably: measured 67 TF at
+// one 128x128 workgroup per CU and 70-72 TF at two (tools/gemm_probe2.hip) vs 56 / 67 TF LDS-staged.
+// A(r,k) = A[r + k*lda], B(c,k) = B[c + k*ldb]; SIGN = -1 accumulates  acc -= A·B^T.
+//
+// Row/column interleave: the wave's MFMA tiles are paired — tile 2p holds the EVEN rows and tile
+// 2p+1 the ODD rows of a 32-row group (same for columns) — so ONE 16-byte load per lane feeds two
+// fragments (half the load instructions, 16-byte L2 accesses), and C is read/written 16 bytes per
+// lane.  Everything outside goes through row_of / col_of, so the permutation is invisible.
+//   accumulator register (m, n, i) of lane l  <->  C(row_of(wr, m, l), col_of(wc, n, i, l))
+// ------------------------------------------------------------------------------------------
+template <int WR_, int WC_, int TM_, int TN_, int D_>
+struct GemmDirect {
+    static constexpr int WR = WR_, WC = WC_, TM = TM_, TN = TN_, D = D_;
+    static constexpr int NWAVES = WR * WC, NTHREADS = 64 * WR * WC;   // 4 or 8 waves per workgroup
+    static_assert(TM % 2 == 0 && TN % 2 == 0, "tiles are paired");
+    static constexpr int BM = WR * TM * 16, BN = WC * TN * 16;
+    static constexpr int PM = TM / 2, PN = TN / 2;
+
+    __device__ static __forceinline__ int row_of(int wr, int m, int lane) {
+        return wr * (TM * 16) + (m >> 1) * 32 + 2 * (lane & 15) + (m & 1);
+    }
+    __device__ static __forceinline__ int col_of(int wc, int n, int i, int lane) {
+        return wc * (TN * 16) + (n >> 1) * 32 + 2 * ((lane >> 4) + 4 * i) + (n & 1);
+    }
+
+    template <int SIGN>
+    __device__ static __forceinline__ void run(const double* __restrict__ A, int lda, const double* __restrict__ B,
+                                               int ldb, int K, v4d (&acc)[TM][TN]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wr = wave / WC, wc = wave % WC;
+        const int aoff = wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda;   // per-lane element offsets
+        const int boff = wc * (TN * 16) + 2 * (lane & 15) + (lane >> 4) * ldb;
+        const int n = K / 4;
+        if (n == 0) return;
+        v2d af[D][PM], bf[D][PN];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int ks = s < n ? s : n - 1;
+            const double* Ak = A + (size_t)(4 * ks) * lda;
+            const double* Bk = B + (size_t)(4 * ks) * ldb;
+#pragma unroll
+            for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+#pragma unroll
+            for (int t = 0; t < PN; ++t) bf[s][t] = *reinterpret_cast<const v2d*>(Bk + boff + t * 32);
+        }
+        for (int k0 = 0; k0 < n; k0 += D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                if (k0 + s < n) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) {
+                            const double b = bf[s][t >> 1][t & 1];
+                            acc[m][t] = mfma_f64(SIGN < 0 ? -b : b, af[s][m >> 1][m & 1], acc[m][t]);
+                        }
+                }
+                int ks = k0 + s + D;
+                ks = ks < n ? ks : n - 1;
+                const double* Ak = A + (size_t)(4 * ks) * lda;
+                const double* Bk = B + (size_t)(4 * ks) * ldb;
+#pragma unroll
+                for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+#pragma unroll
+                for (int t = 0; t < PN; ++t) bf[s][t] = *reinterpret_cast<const v2d*>(Bk + boff + t * 32);
+            }
+        }
+    }
+
+    // acc += A(:,0:K)·Bl(0:K,:) with A streamed from global (ring of D) and the B operand resident in
+    // LDS as Bl[k*ldbl + c] (ldbl even).  No barriers inside; K may differ per wave (triangular A).
+    __device__ static __forceinline__ void run_Blds(const double* __restrict__ A, int lda,
+                                                    const double* __restrict__ Bl, int ldbl, int K,
+                                                    v4d (&acc)[TM][TN]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wr = wave / WC, wc = wave % WC;
+        const int aoff = wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda;
+        const double* Bs = Bl + wc * (TN * 16) + 2 * (lane & 15) + (lane >> 4) * ldbl;
+        const int n = K / 4;
+        if (n == 0) return;
+        v2d af[D][PM];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int ks = s < n ? s : n - 1;
+            const double* Ak = A + (size_t)(4 * ks) * lda;
+#pragma unroll
+            for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+        }
+        for (int k0 = 0; k0 < n; k0 += D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                if (k0 + s < n) {
+                    v2d bf[PN];
+#pragma unroll
+                    for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs + (4 * (k0 + s)) * ldbl + t * 32);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) acc[m][t] = mfma_f64(bf[t >> 1][t & 1], af[s][m >> 1][m & 1], acc[m][t]);
+                }
+                int ks = k0 + s + D;
+                ks = ks < n ? ks : n - 1;
+                const double* Ak = A + (size_t)(4 * ks) * lda;
+#pragma unroll
+                for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+            }
+        }
+    }
+};
+
 }  // namespace boss

@@ -87,23 +87,27 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs
 template <class G>
 struct PredictLds {
     static constexpr int LDR = G::BN + 16;
-    static constexpr int BYTES = (G::LDS_DOUBLES + BLK * LDR + 2 * G::WR * G::BN) * 8;
+    static constexpr int BYTES = (BLK * LDR + 2 * G::WR * G::BN) * 8;
 };
 
+// G = GemmDirect<WR,1,TM,TN,D> with WR·TM·16 = 128: WR waves stacked along the 128 rows, BN = 16·TN candidates.
+// Both GEMMs stream their A operand (L row block / Dinv_i) straight from L2 through a register
+// ring; GEMM1's B operand is the workgroup's own V slab (global, candidate-contiguous), GEMM2's
+// B operand is the R tile in LDS.  Three barriers per row block, none inside the GEMMs.
 template <class G>
-__global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
+__global__ __launch_bounds__(G::NTHREADS) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
                                                       const double* __restrict__ Dinv,
                                                       const double* __restrict__ Xsc,
                                                       const double* __restrict__ Csc, int d, int Mp, int kern,
                                                       double amp2, double* __restrict__ Vscratch,
-                                                      double* __restrict__ ss_out, double* __restrict__ mz_out) {
-    static_assert(G::BM == BLK, "row block must be 128");
+                                                      double* __restrict__ ss_out, double* __restrict__ mz_out, int dbg) {
+    static_assert(G::BM == BLK && G::WC == 1, "row block must be 128 with waves stacked along rows");
     extern __shared__ double lds[];
     constexpr int BN = G::BN, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
-    double* Rs = lds + G::LDS_DOUBLES;
+    double* Rs = lds;
     double* red = Rs + BLK * LDR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / G::WC, wc = wave % G::WC;
+    const int wr = wave, wc = 0;
     const int c0 = blockIdx.x * BN;
     double* V = Vscratch + (size_t)blockIdx.x * Np * BN;
     const int nblk = Np / BLK;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__
         for (int m = 0; m < TM; ++m)
 #pragma unroll
             for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-        G::run(A + (size_t)ib * BLK, ld, V, BN, ib * BLK, acc, lds);
+        if (!(dbg & 4)) G::template run<1>(A + (size_t)ib * BLK, ld, V, BN, ib * BLK, acc);
 
         // K*_ib tile in the accumulator layout
         double r2[TM][TN][4];
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__
             for (int n = 0; n < TN; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) r2[m][n][i] = 0.0;
-        for (int kd = 0; kd < d; ++kd) {
+        for (int kd = 0; kd < ((dbg & 1) ? 0 : d); ++kd) {
             double xr[TM], xc[TN][4];
 #pragma unroll
             for (int m = 0; m < TM; ++m) xr[m] = Xsc[(size_t)kd * Np + ib * BLK + G::row_of(wr, m, lane)];
@@ -156,16 +160,18 @@ __global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__
             for (int n = 0; n < TN; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    double ks = live ? amp2 * kappa_r2(kern, r2[m][n][i]) : 0.0;
+                    double ks = (live && !(dbg & 1)) ? amp2 * kappa_r2(kern, r2[m][n][i]) : 0.0;
                     Rs[row * LDR + G::col_of(wc, n, i, lane)] = ks - acc[m][n][i];
                 }
         }
+        __syncthreads();                                   // R tile complete
         v4d acc2[TM][TN];
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
             for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-        G::run_Blds(Dinv + (size_t)ib * BLK * BLK, BLK, Rs, LDR, BLK, acc2, lds);
+        // Dinv_i is lower triangular: rows of wave w only need k < 32 (w + 1)
+        if (!(dbg & 2)) G::run_Blds(Dinv + (size_t)ib * BLK * BLK, BLK, Rs, LDR, (TM * 16) * (wr + 1), acc2);   // K multiple of 16
 
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
@@ -176,14 +182,14 @@ __global__ __launch_bounds__(256) void predict_kernel(const double* __restrict__
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const double v = acc2[m][n][i];
-                    V[(size_t)row * BN + G::col_of(wc, n, i, lane)] = v;
+                    if (!(dbg & 8)) V[(size_t)row * BN + G::col_of(wc, n, i, lane)] = v;
                     ssp[n][i] = __builtin_fma(v, v, ssp[n][i]);
                     mzp[n][i] = __builtin_fma(v, zr, mzp[n][i]);
                 }
         }
-        __syncthreads();   // V_ib visible to the whole workgroup before it is re-read as a B operand
+        __syncthreads();   // V_ib visible to the whole workgroup (it is the next block's B operand); Rs reusable
     }
-    // reduce over the 16 row-lanes, then over the WR waves stacked along rows
+    // reduce over the 16 row-lanes, then over the 4 waves stacked along rows
 #pragma unroll
     for (int n = 0; n < TN; ++n)
 #pragma unroll

@@ -26,97 +26,164 @@ constexpr int DIAG_LDS_BYTES = (BLK * LDD + BLK) * 8;  // block + reciprocal dia
 // X(r,c) at c*16+r, zero above the diagonal).
 // info: first failing global column + 1 (0 = success) — PosDefException analogue.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Abase, int ld, size_t bstride,
+constexpr int DIAG_THREADS = 1024;   // 16 waves = 4 per SIMD: single-wave fp64 VALU / LDS / MFMA issue rates are 3-5x below the multi-wave rates
+__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ Abase, int ld, size_t bstride,
                                                          int k, double* __restrict__ inv16base,
                                                          size_t inv16_bstride, int* __restrict__ info) {
     extern __shared__ double smem[];
     double* D = smem;
     double* rdiag = smem + BLK * LDD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: tile decode runs on the SALU
     double* A = Abase + (size_t)blockIdx.z * bstride + (size_t)k * BLK * ((size_t)ld + 1);
     double* inv16 = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
 
-    for (int idx = tid; idx < BLK * (BLK / 2); idx += 256) {
+    for (int idx = tid; idx < BLK * (BLK / 2); idx += DIAG_THREADS) {
         int c = idx / (BLK / 2), rp = idx % (BLK / 2);
         *reinterpret_cast<v2d*>(D + c * LDD + 2 * rp) = *reinterpret_cast<const v2d*>(A + (size_t)c * ld + 2 * rp);
     }
     __syncthreads();
+#ifdef BOSS_DIAG_PROFILE
+    unsigned long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc[8], pu[8];
+    unsigned long long tl = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tt[i] += n_ - tl; tl = n_; }
+#else
+#define STAMP(i)
+#endif
 
     int fail = -1;
     for (int jb = 0; jb < 8; ++jb) {
-        // ---- panel of 16 columns: every wave factors the 16×16 diagonal block redundantly in
-        //      lanes 0..15 and carries 48 rows below it in lanes 16..63 --------------------------
-        int row;
-        bool active;
-        if (lane < 16) {
-            row = jb * 16 + lane;
-            active = true;
-        } else {
-            row = (jb + 1) * 16 + wave * 48 + (lane - 16);
-            active = row < BLK;
+        // ---- panel of 16 columns, in registers.  Tiles are held in the "transposed C" layout:
+        //      register i of lane l = element (row = l&15, col = (l>>4) + 4i) of a 16×16 tile, so
+        //      register t IS the 16×4 micro-panel of columns 4t..4t+3 in MFMA A/B-operand layout.
+        //      Every wave factors the (symmetric-filled) diagonal tile redundantly and carries up to
+        //      two of the row tiles below it; each 4-column micro-panel is finished with lane
+        //      shuffles, then ONE rank-4 MFMA per tile updates the remaining columns. ---------------
+        const int r16 = lane & 15, q = lane >> 4;
+        const int t0 = jb + 1 + wave;                               // row tile owned by this wave (16 waves, <= 7 tiles)
+        const bool has0 = t0 < 8;
+        if (wave == 0 || has0) {   // waves without a row tile skip the (redundant) diagonal-tile factorisation
+        v4d S, X0 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = q + 4 * i;
+            const int lo = (r16 >= c) ? ((jb * 16 + c) * LDD + jb * 16 + r16) : ((jb * 16 + r16) * LDD + jb * 16 + c);
+            S[i] = D[lo];
+            if (has0) X0[i] = D[(jb * 16 + c) * LDD + t0 * 16 + r16];
         }
-        double x[16];
+        STAMP(0)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            int col = jb * 16 + c;
-            int addr = (lane < 16 && c > lane) ? (row * LDD + col) : (col * LDD + row);
-            x[c] = active ? D[addr] : 0.0;
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double p = readlane_f64(S[t], 16 * j + 4 * t + j);
+                if (!(p > 0.0)) {                      // NaN or non-positive pivot: not PD
+                    if (fail < 0) fail = k * BLK + jb * 16 + 4 * t + j;
+                    p = 1.0;
+                }
+                const double inv = rsqrt_refined(p);
+                if (tid == 0) rdiag[jb * 16 + 4 * t + j] = inv;
+                const bool colj = (q == j);
+                S[t] = colj ? S[t] * inv : S[t];
+                X0[t] = colj ? X0[t] * inv : X0[t];
+                if (j < 3) {
+                    const int src = 16 * j + r16;          // same row, column j of the micro-panel
+                    const double lS = __shfl(S[t], src), l0 = __shfl(X0[t], src);
+                    double lc = readlane_f64(S[t], 16 * j + 4 * t + j + 1);
+                    if (j < 2) {
+                        const double lc2 = readlane_f64(S[t], 16 * j + 4 * t + j + 2);
+                        lc = (q == j + 2) ? lc2 : lc;
+                    }
+                    if (j < 1) {
+                        const double lc3 = readlane_f64(S[t], 16 * j + 4 * t + j + 3);
+                        lc = (q == j + 3) ? lc3 : lc;
+                    }
+                    const bool upd = q > j;
+                    S[t] = upd ? __builtin_fma(-lS, lc, S[t]) : S[t];
+                    X0[t] = upd ? __builtin_fma(-l0, lc, X0[t]) : X0[t];
+                }
+            }
+            if (t < 3) {
+                // rank-4 update of columns > 4t+3:  X(r,c) -= Σ_k X(r,4t+k) · S(c,4t+k)
+                const double am = (r16 > 4 * t + 3) ? -S[t] : 0.0;
+                const double bS = S[t], b0 = X0[t];
+                S = mfma_f64(am, bS, S);
+                X0 = mfma_f64(am, b0, X0);
+            }
         }
+#ifdef BOSS_DIAG_PROFILE
+        { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc[jb] = n_ - tl; }
+#endif
+        STAMP(1)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double p = readlane_f64(x[j], j);
-            if (!(p > 0.0)) {                      // NaN or non-positive pivot: not PD
-                if (fail < 0) fail = k * BLK + jb * 16 + j;
-                p = 1.0;
-            }
-            double inv = rsqrt_refined(p);
-            if (tid == 0) rdiag[jb * 16 + j] = inv;
-            double lj = x[j] * inv;
-            x[j] = lj;
-#pragma unroll
-            for (int c = j + 1; c < 16; ++c) {
-                double lc = readlane_f64(lj, c);
-                x[c] = __builtin_fma(-lj, lc, x[c]);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int c = q + 4 * i;
+            if (wave == 0 && r16 >= c) D[(jb * 16 + c) * LDD + jb * 16 + r16] = S[i];
+            if (has0) D[(jb * 16 + c) * LDD + t0 * 16 + r16] = X0[i];
         }
-        if (active && (lane >= 16 || wave == 0)) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if (lane >= 16 || c <= lane) D[(jb * 16 + c) * LDD + row] = x[c];
-            }
         }
         __syncthreads();
+        STAMP(2)
         // ---- rank-16 update of the remaining lower 16×16 tiles (MFMA, operands from LDS) -----
         const int t = 7 - jb;
         const int T = t * (t + 1) / 2;
-        for (int q = wave; q < T; q += 4) {
-            int a = 0;
-            while ((a + 1) * (a + 2) / 2 <= q) ++a;
-            int b = q - a * (a + 1) / 2;
-            int ti = jb + 1 + a, tj = jb + 1 + b;
-            v4d cr;
+        // four tiles per wave in flight: their 4-deep MFMA chains interleave and the LDS latency overlaps
+        constexpr int NW = DIAG_THREADS / 64, U = 2;
+        for (int q0 = wave; q0 < T; q0 += U * NW) {
+            int ti[U], tj[U];
+            bool ok[U];
+            v4d cr[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cr[i] = D[(tj * 16 + (lane >> 4) + 4 * i) * LDD + ti * 16 + (lane & 15)];
+            for (int u = 0; u < U; ++u) {
+                const int qq = q0 + NW * u;
+                ok[u] = qq < T;
+                int a = 0;
+                while ((a + 1) * (a + 2) / 2 <= qq) ++a;
+                const int b = qq - a * (a + 1) / 2;
+                ti[u] = ok[u] ? jb + 1 + a : jb + 1;
+                tj[u] = ok[u] ? jb + 1 + b : jb + 1;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                int kc = (jb * 16 + 4 * s + (lane >> 4)) * LDD;
-                double af = D[kc + tj * 16 + (lane & 15)];
-                double bf = D[kc + ti * 16 + (lane & 15)];
-                cr = mfma_f64(-af, bf, cr);
+                for (int i = 0; i < 4; ++i) cr[u][i] = D[(tj[u] * 16 + (lane >> 4) + 4 * i) * LDD + ti[u] * 16 + (lane & 15)];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) D[(tj * 16 + (lane >> 4) + 4 * i) * LDD + ti * 16 + (lane & 15)] = cr[i];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kc = (jb * 16 + 4 * s4 + (lane >> 4)) * LDD + (lane & 15);
+                double af[U], bf[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    af[u] = D[kc + tj[u] * 16];
+                    bf[u] = D[kc + ti[u] * 16];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) cr[u] = mfma_f64(-af[u], bf[u], cr[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ok[u]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) D[(tj[u] * 16 + (lane >> 4) + 4 * i) * LDD + ti[u] * 16 + (lane & 15)] = cr[u][i];
+                }
+            }
         }
+#ifdef BOSS_DIAG_PROFILE
+        { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pu[jb] = n_ - tl; }
+#endif
+        STAMP(6)
         __syncthreads();
+        STAMP(3)
     }
     if (tid == 0 && fail >= 0) {
         if (info[blockIdx.z] == 0) info[blockIdx.z] = fail + 1;
     }
-    // ---- write L (lower part only) -------------------------------------------------------------
-    for (int idx = tid; idx < BLK * BLK; idx += 256) {
-        int c = idx / BLK, r = idx % BLK;
-        if (r >= c) A[(size_t)c * ld + r] = D[c * LDD + r];
+    // ---- write L: 16-byte stores, skipping the 16×16 tiles strictly above the diagonal (the upper
+    //      triangles of the diagonal tiles carry scratch values; nothing reads them) ------------------
+    for (int idx = tid; idx < BLK * (BLK / 2); idx += DIAG_THREADS) {
+        int c = idx / (BLK / 2), rp = idx % (BLK / 2);
+        if ((2 * rp) / 16 >= c / 16)
+            *reinterpret_cast<v2d*>(A + (size_t)c * ld + 2 * rp) = *reinterpret_cast<const v2d*>(D + c * LDD + 2 * rp);
     }
+    STAMP(4)
     // ---- inverses of the eight 16×16 diagonal blocks: lane = column, forward substitution ------
     if (tid < 128) {
         const int blk = tid >> 4, c = tid & 15, base = blk * 16;
@@ -131,6 +198,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Ab
 #pragma unroll
         for (int r = 0; r < 16; ++r) inv16[blk * 256 + c * 16 + r] = xc[r];
     }
+    STAMP(5)
+#ifdef BOSS_DIAG_PROFILE
+    if (tid == 0 && k == 3) printf("cols/panel: %llu %llu %llu %llu %llu %llu %llu %llu  upd/panel: %llu %llu %llu %llu %llu %llu %llu %llu\n", pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7], pu[0], pu[1], pu[2], pu[3], pu[4], pu[5], pu[6], pu[7]);
+    if (tid == 0 && k == 3) printf("diag k=3 cycles: load=%llu cols=%llu store=%llu updwork=%llu updbarrier=%llu writeL=%llu inv16=%llu\n", tt[0], tt[1], tt[2], tt[6], tt[3], tt[4], tt[5]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -214,36 +286,51 @@ __global__ __launch_bounds__(64) void potrf_dinv_kernel(const double* __restrict
 // Trailing update  C_ij -= P_i P_j^T  for the lower block triangle behind panel k, plus the
 // right-hand-side row block (i == m, only its first 32 rows are live).
 // ------------------------------------------------------------------------------------------
-typedef GemmNT<2, 2, 4, 4> SyrkG;     // 128×128 tile
-typedef GemmNT<1, 4, 2, 2> RhsG;      // 32×128 tile for the δ^T row block
-constexpr int SYRK_LDS_BYTES = (SyrkG::LDS_DOUBLES > RhsG::LDS_DOUBLES ? SyrkG::LDS_DOUBLES : RhsG::LDS_DOUBLES) * 8;
+typedef GemmDirect<2, 2, 4, 4, 4> SyrkG;   // 128×128 tile, fragments streamed from L2, no LDS
+typedef GemmDirect<1, 4, 2, 2, 4> RhsG;    // 32×128 tile for the δ^T row block
+constexpr int SYRK_LDS_BYTES = 0;
 
+// acc is INITIALISED from C (its load latency overlaps the operand prologue), updated with
+// acc -= P_i P_j^T, and stored back: the epilogue is pure stores.
 template <class G>
-__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k, int R0, int C0, double* lds) {
+__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k, int R0, int C0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / G::WC, wc = wave % G::WC;
     const double* Pi = A + R0 + (size_t)k * BLK * ld;
     const double* Pj = A + C0 + (size_t)k * BLK * ld;
+    double* C = A + R0 + (size_t)C0 * ld;
     v4d acc[G::TM][G::TN];
+    // rows row_of(m) and row_of(m+1) (m even) are adjacent: one 16-byte access per pair
 #pragma unroll
-    for (int m = 0; m < G::TM; ++m)
-#pragma unroll
-        for (int n = 0; n < G::TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-    G::run(Pi, ld, Pj, ld, BLK, acc, lds);
-#pragma unroll
-    for (int m = 0; m < G::TM; ++m)
+    for (int m = 0; m < G::TM; m += 2)
 #pragma unroll
         for (int n = 0; n < G::TN; ++n)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                size_t off = (size_t)(R0 + G::row_of(wr, m, lane)) + (size_t)(C0 + G::col_of(wc, n, i, lane)) * ld;
-                A[off] -= acc[m][n][i];
+                v2d c2 = *reinterpret_cast<const v2d*>(C + G::row_of(wr, m, lane) + (size_t)G::col_of(wc, n, i, lane) * ld);
+                acc[m][n][i] = c2[0];
+                acc[m + 1][n][i] = c2[1];
+            }
+    G::template run<-1>(Pi, ld, Pj, ld, BLK, acc);
+#pragma unroll
+    for (int m = 0; m < G::TM; m += 2)
+#pragma unroll
+        for (int n = 0; n < G::TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v2d c2 = {acc[m][n][i], acc[m + 1][n][i]};
+                *reinterpret_cast<v2d*>(C + G::row_of(wr, m, lane) + (size_t)G::col_of(wc, n, i, lane) * ld) = c2;
             }
 }
 
-__global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                         int m) {
-    extern __shared__ double lds[];
+// Trailing update behind panel k over the block triangle that starts at block `first` and has m
+// square block rows (+ the δ^T row block at first+m == Np/128):  C_ij -= P_i P_j^T.
+//   potrf_syrk_kernel   all of it (first = k+1) or, with look-ahead, everything beyond the next
+//                       panel (first = k+2) — runs on the side stream, 128×128 tiles;
+//   potrf_colupd_kernel only block column k+1 (the next panel), 32×128 tiles so that this short
+//                       kernel on the critical path is one small round.
+__global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
+                                                            int first, int m) {
     double* A = Abase + (size_t)blockIdx.z * bstride;
     const int t = blockIdx.x;
     const int nsq = m * (m + 1) / 2;
@@ -252,11 +339,20 @@ __global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ Ab
         while ((i + 1) * (i + 2) / 2 <= t) ++i;
         while (i * (i + 1) / 2 > t) --i;
         int j = t - i * (i + 1) / 2;
-        syrk_tile<SyrkG>(A, ld, k, (k + 1 + i) * BLK, (k + 1 + j) * BLK, lds);
+        syrk_tile<SyrkG>(A, ld, k, (first + i) * BLK, (first + j) * BLK);
     } else {
         int j = t - nsq;
-        syrk_tile<RhsG>(A, ld, k, (k + 1 + m) * BLK, (k + 1 + j) * BLK, lds);
+        syrk_tile<RhsG>(A, ld, k, (first + m) * BLK, (first + j) * BLK);
     }
+}
+
+__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
+                                                              int m) {
+    // tiles: 4 per 128-row block of column k+1 (m blocks), then one 32-row tile of the δ^T rows
+    double* A = Abase + (size_t)blockIdx.z * bstride;
+    const int t = blockIdx.x;
+    const int R0 = (t < 4 * m) ? (k + 1) * BLK + t * 32 : (k + 1 + m) * BLK;
+    syrk_tile<RhsG>(A, ld, k, R0, (k + 1) * BLK);
 }
 
 // logdet = 2 Σ_{i<N} log L_ii ,  zz = Σ_{j<N} z_j²   →  scal[2*b], scal[2*b+1]
