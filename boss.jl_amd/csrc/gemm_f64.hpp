@@ -187,6 +187,19 @@ struct GemmNT {
 // lane.  Everything outside goes through row_of / col_of, so the permutation is invisible.
 //   accumulator register (m, n, i) of lane l  <->  C(row_of(wr, m, l), col_of(wc, n, i, l))
 // ------------------------------------------------------------------------------------------
+// Ring loads are inline asm so that hipcc can neither sink them towards their use (it does, to cut
+// register pressure, which collapses the prefetch distance) nor insert its own conservative
+// s_waitcnt; the waits are hand-counted (loads complete in order: waiting for vmcnt(n) retires
+// everything but the n most recent vector-memory operations).
+__device__ __forceinline__ void gld16(v2d& dst, const double* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int WR_, int WC_, int TM_, int TN_, int D_>
 struct GemmDirect {
     static constexpr int WR = WR_, WC = WC_, TM = TM_, TN = TN_, D = D_;
@@ -212,36 +225,54 @@ struct GemmDirect {
         const int n = K / 4;
         if (n == 0) return;
         v2d af[D][PM], bf[D][PN];
+        static_assert((PM + PN) * (D - 1) <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
         for (int s = 0; s < D; ++s) {
             const int ks = s < n ? s : n - 1;
             const double* Ak = A + (size_t)(4 * ks) * lda;
             const double* Bk = B + (size_t)(4 * ks) * ldb;
 #pragma unroll
-            for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+            for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
 #pragma unroll
-            for (int t = 0; t < PN; ++t) bf[s][t] = *reinterpret_cast<const v2d*>(Bk + boff + t * 32);
+            for (int t = 0; t < PN; ++t) gld16(bf[s][t], Bk + boff + t * 32);
         }
-        for (int k0 = 0; k0 < n; k0 += D) {
+        // Main loop: whole ring passes, branch-free.  Before slot s is consumed exactly
+        // (PM+PN)(D-1) younger ring loads are in flight (every pass re-issues every slot, clamped).
+        const int npass = n / D;
+        for (int g = 0; g < npass; ++g) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
-                if (k0 + s < n) {
+                wait_vmcnt<(PM + PN) * (D - 1)>();
 #pragma unroll
-                    for (int m = 0; m < TM; ++m)
+                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                        for (int t = 0; t < TN; ++t) {
-                            const double b = bf[s][t >> 1][t & 1];
-                            acc[m][t] = mfma_f64(SIGN < 0 ? -b : b, af[s][m >> 1][m & 1], acc[m][t]);
-                        }
-                }
-                int ks = k0 + s + D;
+                    for (int t = 0; t < TN; ++t) {
+                        const double b = bf[s][t >> 1][t & 1];
+                        acc[m][t] = mfma_f64(SIGN < 0 ? -b : b, af[s][m >> 1][m & 1], acc[m][t]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                int ks = (g + 1) * D + s;
                 ks = ks < n ? ks : n - 1;
                 const double* Ak = A + (size_t)(4 * ks) * lda;
                 const double* Bk = B + (size_t)(4 * ks) * ldb;
 #pragma unroll
-                for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+                for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
 #pragma unroll
-                for (int t = 0; t < PN; ++t) bf[s][t] = *reinterpret_cast<const v2d*>(Bk + boff + t * 32);
+                for (int t = 0; t < PN; ++t) gld16(bf[s][t], Bk + boff + t * 32);
+            }
+        }
+        wait_vmcnt<0>();                        // ring drained: the (clamped) reloads of the last pass
+        const int rem = n - npass * D;          // < D k-substeps left; their operands are already in the ring
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            if (s < rem) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const double b = bf[s][t >> 1][t & 1];
+                        acc[m][t] = mfma_f64(SIGN < 0 ? -b : b, af[s][m >> 1][m & 1], acc[m][t]);
+                    }
             }
         }
     }
@@ -263,25 +294,40 @@ struct GemmDirect {
             const int ks = s < n ? s : n - 1;
             const double* Ak = A + (size_t)(4 * ks) * lda;
 #pragma unroll
-            for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+            for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
         }
-        for (int k0 = 0; k0 < n; k0 += D) {
+        const int npass = n / D;
+        for (int g = 0; g < npass; ++g) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
-                if (k0 + s < n) {
-                    v2d bf[PN];
+                v2d bf[PN];
 #pragma unroll
-                    for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs + (4 * (k0 + s)) * ldbl + t * 32);
+                for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs + (4 * (g * D + s)) * ldbl + t * 32);
+                wait_vmcnt<PM * (D - 1)>();
 #pragma unroll
-                    for (int m = 0; m < TM; ++m)
+                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                        for (int t = 0; t < TN; ++t) acc[m][t] = mfma_f64(bf[t >> 1][t & 1], af[s][m >> 1][m & 1], acc[m][t]);
-                }
-                int ks = k0 + s + D;
+                    for (int t = 0; t < TN; ++t) acc[m][t] = mfma_f64(bf[t >> 1][t & 1], af[s][m >> 1][m & 1], acc[m][t]);
+                __builtin_amdgcn_sched_barrier(0);
+                int ks = (g + 1) * D + s;
                 ks = ks < n ? ks : n - 1;
                 const double* Ak = A + (size_t)(4 * ks) * lda;
 #pragma unroll
-                for (int m = 0; m < PM; ++m) af[s][m] = *reinterpret_cast<const v2d*>(Ak + aoff + m * 32);
+                for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
+            }
+        }
+        wait_vmcnt<0>();
+        const int rem = n - npass * D;
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            if (s < rem) {
+                v2d bf[PN];
+#pragma unroll
+                for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs + (4 * (npass * D + s)) * ldbl + t * 32);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[m][t] = mfma_f64(bf[t >> 1][t & 1], af[s][m >> 1][m & 1], acc[m][t]);
             }
         }
     }

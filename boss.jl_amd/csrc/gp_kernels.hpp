@@ -95,7 +95,7 @@ struct PredictLds {
 // ring; GEMM1's B operand is the workgroup's own V slab (global, candidate-contiguous), GEMM2's
 // B operand is the R tile in LDS.  Three barriers per row block, none inside the GEMMs.
 template <class G>
-__global__ __launch_bounds__(G::NTHREADS) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
+__global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
                                                       const double* __restrict__ Dinv,
                                                       const double* __restrict__ Xsc,
                                                       const double* __restrict__ Csc, int d, int Mp, int kern,
