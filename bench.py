@@ -49,6 +49,21 @@ def flops_acq_eval(N, d):
     return N ** 2 + N * (3 * d + 20) + 4 * N
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_summary.json): FETCH_SIZE (KB, doubled — on gfx950 it reports half the bytes of
+    16-B/lane streaming reads, MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KB)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        d = json.load(open(path))
+        for k, v in d.items():
+            if kernel_substr in k:
+                return (2.0 * v["fetch_kb_raw"] + v["write_kb"]) * 1024.0
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(X, y, Xs, lam):
     """The CPU oracle on this host's cores: one posterior update (dpotrf + 2 dtrsv) and a bounded
     sample of acquisition evaluations in the reference's call pattern (one dtrsv per candidate,
@@ -169,15 +184,19 @@ def main():
         fl_pred = M_CAND * flops_acq_eval(N_OBS, D)                         # algorithmic flops per launch
         ach = fl_pred / (ms_pred / n_pred * 1e-3) / 1e12
         roof = {"kernel": "predict_kernel", "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("predict_kernel"),
+                "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 16-B/lane correction] + WRITE_SIZE, x1024; profiles/r01_pmc_summary.json)",
                 "avg_launch_ms": ms_pred / n_pred, "flops_per_launch": fl_pred}
+        # the factorisation: N^3/3 over the whole posterior update (two-stream look-ahead; the
+        # per-class event times below come from the serialised profiling pass)
         fl_potrf = N_OBS ** 3 / 3
-        t_potrf = (ms_syrk + ms_diag + ms_trsm) / reps * 1e-3
-        ach2 = fl_potrf / t_potrf / 1e12
-        roof_potrf = {"kernel": "potrf (diag+trsm+syrk launches)", "bound": "mfma", "achieved": ach2,
+        t_upd_s = t_upd / args.steps
+        ach2 = fl_potrf / t_upd_s / 1e12
+        roof_potrf = {"kernel": "posterior update (gram + look-ahead Cholesky + logdet)", "bound": "mfma", "achieved": ach2,
                       "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach2 / FP64_MFMA_PEAK_TFLOPS,
-                      "ms_per_factorisation": t_potrf * 1e3,
-                      "ms_diag": ms_diag / reps, "ms_trsm": ms_trsm / reps, "ms_syrk": ms_syrk / reps}
+                      "ms_per_update": t_upd_s * 1e3,
+                      "serialised_ms_diag": ms_diag / reps, "serialised_ms_trsm": ms_trsm / reps,
+                      "serialised_ms_syrk": ms_syrk / reps}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

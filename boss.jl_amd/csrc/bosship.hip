@@ -57,7 +57,7 @@ struct Ctx {
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
-    Workspace vscratch, csc, pred, batchA, batchX, batchMisc;
+    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc;
     void* pinned = nullptr;   // small host-pinned result area
     std::mutex mtx;
 };
@@ -603,7 +603,6 @@ extern "C" int boss_gp_loglike_batch(int device, int kernel, int d, int N, const
             mean_arg = meandev;
         }
         HIPCHK(hipMemsetAsync(info, 0, sizeof(int) * nb, s));
-        HIPCHK(hipMemsetAsync(A, 0, per * nb, s));
         {
             ProfScope ps(c, "prep");
             hipLaunchKernelGGL(scale_points_kernel, dim3((Np + 255) / 256, 1, nb), dim3(256), 0, s, Xraw, Xsc, xs_bstride,
@@ -801,8 +800,11 @@ extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_
     const int M = cand->M;
     // device scratch: mu[P][M] | var[P][M] | acq[M] | mean[P][M] | coefs[P] | ymax[P] | out val | out idx | mask
     const size_t nd = (size_t)3 * P * M + M + 2 * P + 4;
-    double* dev = nullptr;
-    if (hipMalloc((void**)&dev, sizeof(double) * nd + M) != hipSuccess) return fail(BOSS_E_ALLOC, "device allocation failed");
+    {
+        int rc = ws_reserve(c->acq, sizeof(double) * nd + M);      // grow-only: no hipMalloc/hipFree (= device sync) per call
+        if (rc) return rc;
+    }
+    double* dev = (double*)c->acq.p;
     double* dmu = dev;
     double* dvar = dmu + (size_t)P * M;
     double* dacq = dvar + (size_t)P * M;
@@ -812,10 +814,7 @@ extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_
     double* dval = dymax + P;
     long* didx = (long*)(dval + 1);
     unsigned char* dmask = (unsigned char*)(dev + nd);
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(s);
-        (void)hipFree(dev);
-    };
+    auto cleanup = [&]() { (void)hipStreamSynchronize(s); };
     (void)hipMemcpyAsync(dcoef, fit_coefs, sizeof(double) * P, hipMemcpyHostToDevice, s);
     if (y_max) (void)hipMemcpyAsync(dymax, y_max, sizeof(double) * P, hipMemcpyHostToDevice, s);
     if (valid_mask) (void)hipMemcpyAsync(dmask, valid_mask, M, hipMemcpyHostToDevice, s);

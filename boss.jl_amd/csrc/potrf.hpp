@@ -17,7 +17,7 @@
 namespace boss {
 
 constexpr int LDD = 144;                               // LDS leading dim of the diagonal block
-constexpr int DIAG_LDS_BYTES = (BLK * LDD + BLK) * 8;  // block + reciprocal diagonal
+constexpr int DIAG_LDS_BYTES = (BLK * LDD + 256) * 8;  // block + E tile of the current panel
 
 // ------------------------------------------------------------------------------------------
 // Diagonal block: unblocked 16-column panels (lane = row, pivots broadcast with v_readlane),
@@ -27,14 +27,80 @@ constexpr int DIAG_LDS_BYTES = (BLK * LDD + BLK) * 8;  // block + reciprocal dia
 // info: first failing global column + 1 (0 = success) — PosDefException analogue.
 // ------------------------------------------------------------------------------------------
 constexpr int DIAG_THREADS = 1024;   // 16 waves = 4 per SIMD: single-wave fp64 VALU / LDS / MFMA issue rates are 3-5x below the multi-wave rates
+
+// 16×16 tile in the "transposed C" layout: register i of lane l = element (row = l&15, col = (l>>4)+4i),
+// so register t IS the 16×4 micro-panel of columns 4t..4t+3 in MFMA A/B-operand layout.
+//
+// chol16_with_inverse: factor the symmetric-filled tile S in place (lower part = L16) and carry the
+// identity tile E through the same column operations, which leaves E = L16^{-T} (so inv(L16) comes
+// out of the factorisation itself).  Each 4-column micro-panel is finished with lane shuffles
+// (pivot broadcast by v_readlane), then ONE rank-4 MFMA per tile updates the remaining columns.
+__device__ __forceinline__ void chol16_with_inverse(v4d& S, v4d& E, int lane, int col0, int& fail) {
+    const int r16 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) E[i] = (r16 == q + 4 * i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double p = readlane_f64(S[t], 16 * j + 4 * t + j);
+            if (!(p > 0.0)) {                      // NaN or non-positive pivot: not PD
+                if (fail < 0) fail = col0 + 4 * t + j;
+                p = 1.0;
+            }
+            const double inv = rsqrt_refined(p);
+            const bool colj = (q == j);
+            S[t] = colj ? S[t] * inv : S[t];
+            E[t] = colj ? E[t] * inv : E[t];
+            if (j < 3) {
+                const int src = 16 * j + r16;          // same row, column j of the micro-panel
+                const double lS = __shfl(S[t], src), lE = __shfl(E[t], src);
+                double lc = readlane_f64(S[t], 16 * j + 4 * t + j + 1);
+                if (j < 2) {
+                    const double lc2 = readlane_f64(S[t], 16 * j + 4 * t + j + 2);
+                    lc = (q == j + 2) ? lc2 : lc;
+                }
+                if (j < 1) {
+                    const double lc3 = readlane_f64(S[t], 16 * j + 4 * t + j + 3);
+                    lc = (q == j + 3) ? lc3 : lc;
+                }
+                const bool upd = q > j;
+                S[t] = upd ? __builtin_fma(-lS, lc, S[t]) : S[t];
+                E[t] = upd ? __builtin_fma(-lE, lc, E[t]) : E[t];
+            }
+        }
+        if (t < 3) {
+            // rank-4 update of columns > 4t+3:  X(r,c) -= Σ_k X(r,4t+k) · S(c,4t+k)
+            const double am = (r16 > 4 * t + 3) ? -S[t] : 0.0;
+            const double bS = S[t], bE = E[t];
+            S = mfma_f64(am, bS, S);
+            E = mfma_f64(am, bE, E);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagonal block (128×128, LDS-resident), 16-column panels, look-ahead inside the block:
+//   phase A  wave 0 alone runs the sequential pivot chain on the diagonal 16×16 tile
+//            (chol16_with_inverse) — meanwhile waves 1..15 are still applying the PREVIOUS panel's
+//            rank-16 update to the rest of the block;
+//   phase B  waves 1..7-jb turn their row tile into P = X · inv(L16)^T with 4 MFMAs;
+//   phase C  wave 0 updates only the NEXT diagonal tile and goes straight back to phase A,
+//            the other waves update everything else.
+// inv16 out: for each of the 8 diagonal 16×16 blocks its inverse X (column-major 16×16,
+// X(r,c) at c*16+r, zero above the diagonal).
+// info: first failing global column + 1 (0 = success) — PosDefException analogue.
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ Abase, int ld, size_t bstride,
-                                                         int k, double* __restrict__ inv16base,
-                                                         size_t inv16_bstride, int* __restrict__ info) {
+                                                                  int k, double* __restrict__ inv16base,
+                                                                  size_t inv16_bstride, int* __restrict__ info) {
     extern __shared__ double smem[];
     double* D = smem;
-    double* rdiag = smem + BLK * LDD;
+    double* Es = smem + BLK * LDD;                   // E = L16^{-T} of the current panel, row-major 16×16
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: tile decode runs on the SALU
+    const int r16 = lane & 15, q = lane >> 4;
+    constexpr int NW = DIAG_THREADS / 64;
     double* A = Abase + (size_t)blockIdx.z * bstride + (size_t)k * BLK * ((size_t)ld + 1);
     double* inv16 = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
 
@@ -43,137 +109,103 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
         *reinterpret_cast<v2d*>(D + c * LDD + 2 * rp) = *reinterpret_cast<const v2d*>(A + (size_t)c * ld + 2 * rp);
     }
     __syncthreads();
-#ifdef BOSS_DIAG_PROFILE
-    unsigned long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long pc[8], pu[8];
-    unsigned long long tl = __builtin_amdgcn_s_memtime();
-#define STAMP(i) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); tt[i] += n_ - tl; tl = n_; }
-#else
-#define STAMP(i)
-#endif
 
     int fail = -1;
+    v4d S = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                 // symmetric fill of diagonal tile 0 from its lower part
+            const int c = q + 4 * i;
+            S[i] = D[(r16 >= c) ? (c * LDD + r16) : (r16 * LDD + c)];
+        }
+    }
     for (int jb = 0; jb < 8; ++jb) {
-        // ---- panel of 16 columns, in registers.  Tiles are held in the "transposed C" layout:
-        //      register i of lane l = element (row = l&15, col = (l>>4) + 4i) of a 16×16 tile, so
-        //      register t IS the 16×4 micro-panel of columns 4t..4t+3 in MFMA A/B-operand layout.
-        //      Every wave factors the (symmetric-filled) diagonal tile redundantly and carries up to
-        //      two of the row tiles below it; each 4-column micro-panel is finished with lane
-        //      shuffles, then ONE rank-4 MFMA per tile updates the remaining columns. ---------------
-        const int r16 = lane & 15, q = lane >> 4;
-        const int t0 = jb + 1 + wave;                               // row tile owned by this wave (16 waves, <= 7 tiles)
-        const bool has0 = t0 < 8;
-        if (wave == 0 || has0) {   // waves without a row tile skip the (redundant) diagonal-tile factorisation
-        v4d S, X0 = {0.0, 0.0, 0.0, 0.0};
+        const int t = 7 - jb;                         // row tiles below the diagonal tile
+        // ---------------- phase A ----------------
+        if (wave == 0) {
+            v4d E;
+            chol16_with_inverse(S, E, lane, k * BLK + jb * 16, fail);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = q + 4 * i;
-            const int lo = (r16 >= c) ? ((jb * 16 + c) * LDD + jb * 16 + r16) : ((jb * 16 + r16) * LDD + jb * 16 + c);
-            S[i] = D[lo];
-            if (has0) X0[i] = D[(jb * 16 + c) * LDD + t0 * 16 + r16];
-        }
-        STAMP(0)
+            for (int i = 0; i < 4; ++i) {
+                const int c = q + 4 * i;
+                if (r16 >= c) D[(jb * 16 + c) * LDD + jb * 16 + r16] = S[i];
+                Es[r16 * 16 + c] = E[i];                                  // E(row r16, col c)
+                inv16[jb * 256 + r16 * 16 + c] = E[i];                    // inv(L16)(c, r16) = E(r16, c)
+            }
+        } else if (jb > 0) {
+            // rest of the rank-16 update with panel jb-1 (tile (jb,jb) was done by wave 0 in phase C)
+            const int jp = jb - 1, tp = 7 - jp;
+            const int T = tp * (tp + 1) / 2;
+            constexpr int U = 2;
+            for (int q0 = wave; q0 < T; q0 += U * (NW - 1)) {   // waves 1..15 cover tile indices 1..T-1
+                int ti[U], tj[U];
+                bool ok[U];
+                v4d cr[U];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+                for (int u = 0; u < U; ++u) {
+                    const int qq = q0 + (NW - 1) * u;
+                    ok[u] = qq < T;
+                    int a = 0;
+                    while ((a + 1) * (a + 2) / 2 <= qq) ++a;
+                    const int b = qq - a * (a + 1) / 2;
+                    ti[u] = ok[u] ? jp + 1 + a : jp + 2;
+                    tj[u] = ok[u] ? jp + 1 + b : jp + 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double p = readlane_f64(S[t], 16 * j + 4 * t + j);
-                if (!(p > 0.0)) {                      // NaN or non-positive pivot: not PD
-                    if (fail < 0) fail = k * BLK + jb * 16 + 4 * t + j;
-                    p = 1.0;
+                    for (int i = 0; i < 4; ++i) cr[u][i] = D[(tj[u] * 16 + q + 4 * i) * LDD + ti[u] * 16 + r16];
                 }
-                const double inv = rsqrt_refined(p);
-                if (tid == 0) rdiag[jb * 16 + 4 * t + j] = inv;
-                const bool colj = (q == j);
-                S[t] = colj ? S[t] * inv : S[t];
-                X0[t] = colj ? X0[t] * inv : X0[t];
-                if (j < 3) {
-                    const int src = 16 * j + r16;          // same row, column j of the micro-panel
-                    const double lS = __shfl(S[t], src), l0 = __shfl(X0[t], src);
-                    double lc = readlane_f64(S[t], 16 * j + 4 * t + j + 1);
-                    if (j < 2) {
-                        const double lc2 = readlane_f64(S[t], 16 * j + 4 * t + j + 2);
-                        lc = (q == j + 2) ? lc2 : lc;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int kc = (jp * 16 + 4 * s4 + q) * LDD + r16;
+                    double af[U], bf[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        af[u] = D[kc + tj[u] * 16];
+                        bf[u] = D[kc + ti[u] * 16];
                     }
-                    if (j < 1) {
-                        const double lc3 = readlane_f64(S[t], 16 * j + 4 * t + j + 3);
-                        lc = (q == j + 3) ? lc3 : lc;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) cr[u] = mfma_f64(-af[u], bf[u], cr[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (ok[u]) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) D[(tj[u] * 16 + q + 4 * i) * LDD + ti[u] * 16 + r16] = cr[u][i];
                     }
-                    const bool upd = q > j;
-                    S[t] = upd ? __builtin_fma(-lS, lc, S[t]) : S[t];
-                    X0[t] = upd ? __builtin_fma(-l0, lc, X0[t]) : X0[t];
                 }
             }
-            if (t < 3) {
-                // rank-4 update of columns > 4t+3:  X(r,c) -= Σ_k X(r,4t+k) · S(c,4t+k)
-                const double am = (r16 > 4 * t + 3) ? -S[t] : 0.0;
-                const double bS = S[t], b0 = X0[t];
-                S = mfma_f64(am, bS, S);
-                X0 = mfma_f64(am, b0, X0);
+        }
+        __syncthreads();                              // barrier 1: L16/E published, block fully updated through panel jb-1
+        if (t == 0) break;
+        // ---------------- phase B: row tiles  P = X · inv(L16)^T ----------------
+        if (wave >= 1 && wave <= t) {
+            const int tr = jb + wave;
+            v4d P = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double aop = Es[(4 * s4 + q) * 16 + r16];                       // inv(L16)(c = r16, k = 4s+q)
+                const double bop = D[(jb * 16 + q + 4 * s4) * LDD + tr * 16 + r16];   // X(r16, k = 4s+q)
+                P = mfma_f64(aop, bop, P);
             }
-        }
-#ifdef BOSS_DIAG_PROFILE
-        { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc[jb] = n_ - tl; }
-#endif
-        STAMP(1)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = q + 4 * i;
-            if (wave == 0 && r16 >= c) D[(jb * 16 + c) * LDD + jb * 16 + r16] = S[i];
-            if (has0) D[(jb * 16 + c) * LDD + t0 * 16 + r16] = X0[i];
+            for (int i = 0; i < 4; ++i) D[(jb * 16 + q + 4 * i) * LDD + tr * 16 + r16] = P[i];
         }
-        }
-        __syncthreads();
-        STAMP(2)
-        // ---- rank-16 update of the remaining lower 16×16 tiles (MFMA, operands from LDS) -----
-        const int t = 7 - jb;
-        const int T = t * (t + 1) / 2;
-        // four tiles per wave in flight: their 4-deep MFMA chains interleave and the LDS latency overlaps
-        constexpr int NW = DIAG_THREADS / 64, U = 2;
-        for (int q0 = wave; q0 < T; q0 += U * NW) {
-            int ti[U], tj[U];
-            bool ok[U];
-            v4d cr[U];
+        __syncthreads();                              // barrier 2: panel jb final
+        // ---------------- phase C (wave 0): next diagonal tile only ----------------
+        if (wave == 0) {
+            const int tn = jb + 1;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int qq = q0 + NW * u;
-                ok[u] = qq < T;
-                int a = 0;
-                while ((a + 1) * (a + 2) / 2 <= qq) ++a;
-                const int b = qq - a * (a + 1) / 2;
-                ti[u] = ok[u] ? jb + 1 + a : jb + 1;
-                tj[u] = ok[u] ? jb + 1 + b : jb + 1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cr[u][i] = D[(tj[u] * 16 + (lane >> 4) + 4 * i) * LDD + ti[u] * 16 + (lane & 15)];
+            for (int i = 0; i < 4; ++i) {
+                const int c = q + 4 * i;
+                S[i] = D[(r16 >= c) ? ((tn * 16 + c) * LDD + tn * 16 + r16) : ((tn * 16 + r16) * LDD + tn * 16 + c)];
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const int kc = (jb * 16 + 4 * s4 + (lane >> 4)) * LDD + (lane & 15);
-                double af[U], bf[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    af[u] = D[kc + tj[u] * 16];
-                    bf[u] = D[kc + ti[u] * 16];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) cr[u] = mfma_f64(-af[u], bf[u], cr[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (ok[u]) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) D[(tj[u] * 16 + (lane >> 4) + 4 * i) * LDD + ti[u] * 16 + (lane & 15)] = cr[u][i];
-                }
+                const double pf = D[(jb * 16 + 4 * s4 + q) * LDD + tn * 16 + r16];
+                S = mfma_f64(-pf, pf, S);
             }
         }
-#ifdef BOSS_DIAG_PROFILE
-        { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pu[jb] = n_ - tl; }
-#endif
-        STAMP(6)
-        __syncthreads();
-        STAMP(3)
     }
-    if (tid == 0 && fail >= 0) {
+    if (wave == 0 && lane == 0 && fail >= 0) {
         if (info[blockIdx.z] == 0) info[blockIdx.z] = fail + 1;
     }
     // ---- write L: 16-byte stores, skipping the 16×16 tiles strictly above the diagonal (the upper
@@ -183,26 +215,6 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
         if ((2 * rp) / 16 >= c / 16)
             *reinterpret_cast<v2d*>(A + (size_t)c * ld + 2 * rp) = *reinterpret_cast<const v2d*>(D + c * LDD + 2 * rp);
     }
-    STAMP(4)
-    // ---- inverses of the eight 16×16 diagonal blocks: lane = column, forward substitution ------
-    if (tid < 128) {
-        const int blk = tid >> 4, c = tid & 15, base = blk * 16;
-        double xc[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int kk = 0; kk < r; ++kk) s = __builtin_fma(-D[(base + kk) * LDD + base + r], xc[kk], s);
-            xc[r] = s * rdiag[base + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) inv16[blk * 256 + c * 16 + r] = xc[r];
-    }
-    STAMP(5)
-#ifdef BOSS_DIAG_PROFILE
-    if (tid == 0 && k == 3) printf("cols/panel: %llu %llu %llu %llu %llu %llu %llu %llu  upd/panel: %llu %llu %llu %llu %llu %llu %llu %llu\n", pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], pc[6], pc[7], pu[0], pu[1], pu[2], pu[3], pu[4], pu[5], pu[6], pu[7]);
-    if (tid == 0 && k == 3) printf("diag k=3 cycles: load=%llu cols=%llu store=%llu updwork=%llu updbarrier=%llu writeL=%llu inv16=%llu\n", tt[0], tt[1], tt[2], tt[6], tt[3], tt[4], tt[5]);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -73,6 +73,51 @@ def timing(d=8, N=4096, M=8192):
     api.prof_enable(0, False)
 
 
+def batch_cfg(S=512, N=1024, d=8):
+    """BASELINE config 5: S hyper-parameter sets, each its own N=1024 Cholesky."""
+    X, y, _ = problem(d, N, 1, seed=4)
+    rng = np.random.default_rng(4)
+    lam = np.exp(-0.7 + 0.3 * rng.standard_normal((d, S)))
+    amp = np.exp(0.3 * rng.standard_normal(S))
+    sig = np.exp(-3 + 0.3 * rng.standard_normal(S))
+    api.loglike_batch(X, y, "matern52", lam[:, :8], amp[:8], sig[:8])
+    t = time.time()
+    ll, st = api.loglike_batch(X, y, "matern52", lam, amp, sig)
+    t1 = time.time() - t
+    t = time.time()
+    ll, st = api.loglike_batch(X, y, "matern52", lam, amp, sig)
+    dt = time.time() - t
+    want = [O.gp_data_loglike_slice(X, y, "matern52", lam[:, s], amp[s], sig[s]) for s in (0, 7, S - 1)]
+    err = max(abs(ll[s] - w) / (1 + abs(w)) for s, w in zip((0, 7, S - 1), want))
+    fl = S * (N ** 3 / 3)
+    print(f"loglike_batch S={S} N={N}: first {t1*1e3:.1f} ms, steady {dt*1e3:.1f} ms  ({S/dt:.0f} factorizations/s, {fl/dt/1e12:.2f} TF)  rel err {err:.1e} ok={int((st==0).sum())}", flush=True)
+
+
+def multi_output(N=2048, d=6, M=8192):
+    """BASELINE config 4: 2 constrained outputs, parametric mean, N=2048 d=6."""
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), np.cos(2 * X).sum(0) - 1.0]) + 0.05 * rng.standard_normal((2, N))
+    Xs = rng.uniform(0, 1, (d, M))
+    th = np.array([0.1, 0.2])
+    mX = [th[0] + th[1] * X.sum(0), th[0] - th[1] * X.sum(0)]
+    ms = np.stack([th[0] + th[1] * Xs.sum(0), th[0] - th[1] * Xs.sum(0)])[None]
+    lam = np.full(d, 0.5)
+    gps = [api.GP(X, Y[p], "matern52") for p in range(2)]
+    cand = api.Candidates(Xs)
+    for _ in range(2):
+        t = time.time()
+        for p in range(2):
+            gps[p].update(lam, 1.0, 0.05, mean_X=mX[p])
+        t_fit = time.time() - t
+        t = time.time()
+        acq, am, mx = api.acq_ei([gps], cand, [1.0, 0.0], [np.inf, 0.5], float(Y[0].max()), None, ms)
+        t_acq = time.time() - t
+    posts = [O.gp_fit(X, Y[p], "matern52", lam, 1.0, 0.05, mean=mX[p]) for p in range(2)]
+    want = O.ei_acquisition(posts, Xs[:, :256], [1.0, 0.0], [np.inf, 0.5], float(Y[0].max()), means_s=[ms[0, 0, :256], ms[0, 1, :256]])
+    print(f"multi-output N={N} P=2 M={M}: fit {t_fit*1e3:.2f} ms, acq {t_acq*1e3:.2f} ms ({M/t_acq/1e6:.2f} M evals/s)  |dacq|={np.abs(acq[:256]-want).max():.1e}", flush=True)
+
+
 if __name__ == "__main__":
     stages = sys.argv[1:] or ["mfma", "parity", "timing"]
     if "mfma" in stages:
@@ -87,3 +132,7 @@ if __name__ == "__main__":
         parity(8, 4096, 512)
     if "timing" in stages:
         timing()
+    if "batch" in stages:
+        batch_cfg()
+    if "multi" in stages:
+        multi_output()
