@@ -9,7 +9,7 @@ from . import api  # noqa: F401
 from .api import (BossError, Candidates, DomainError, GP, PosDefException, acq_ei, fit,  # noqa: F401
                   load_library, loglike_batch)
 from .problem import (BossOptions, BossProblem, Dirac, Domain, ExperimentData, ExpectedImprovement,  # noqa: F401,E402
-                      LinFitness, LogNormal, MvDirac, MvLogNormal)
+                      LinFitness, LogNormal, MvDirac, MvLogNormal, NonlinFitness)
 from .model import HipGaussianProcess, HipGPParams, average_mean  # noqa: F401,E402
 from .fitter import HipBatchedMAP, MAPParams  # noqa: F401,E402
 from .maximizer import HipBatchAM  # noqa: F401,E402

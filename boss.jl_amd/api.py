@@ -42,6 +42,7 @@ SIGNATURES = {
     "boss_gp_loglike_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
                                         C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
     "boss_gp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
+    "boss_gp_predict_cov": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_cand_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.POINTER(C.c_void_p)]),
     "boss_cand_free": (None, [C.c_void_p]),
     "boss_acq_ei": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, _c_dp, _c_dp, _c_dp, C.c_int,
@@ -206,6 +207,24 @@ class GP:
             raise e
         _check(rc)
         return mu, var
+
+    def predict_cov(self, Xs, mean_Xs=None):
+        """mean_and_cov(post, X::Matrix): returns (mu[M], cov[M,M]) with the diagonal clipped."""
+        Xs = _f64(Xs, 2)
+        if Xs.shape[0] != self.d:
+            raise ValueError("candidates must be d×M")
+        M = Xs.shape[1]
+        ms = None if mean_Xs is None else _f64(np.asarray(mean_Xs).reshape(-1), 1)
+        mu = np.zeros(M)
+        cov = np.zeros((M, M), order="F")
+        bad = C.c_long(-1)
+        rc = load_library().boss_gp_predict_cov(self._h, M, _dp(Xs), _dp(ms), _dp(mu), _dp(cov), C.byref(bad))
+        if rc == BOSS_E_NEG_VAR:
+            e = DomainError(rc, load_library().boss_last_error().decode())
+            e.bad_index = bad.value
+            raise e
+        _check(rc)
+        return mu, cov
 
     def close(self):
         if getattr(self, "_h", None):

@@ -782,6 +782,59 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
     return BOSS_OK;
 }
 
+extern "C" int boss_gp_predict_cov(boss_gp_t* g, int M, const double* Xs, const double* mean_Xs, double* mu,
+                                   double* cov, long* bad_index) {
+    if (!g || !Xs || !mu || !cov) return fail(BOSS_E_INVALID, "NULL argument");
+    if (M < 1) return fail(BOSS_E_INVALID, "M must be >= 1");
+    if (bad_index) *bad_index = -1;
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    boss_cand_t* cd = nullptr;
+    int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
+    if (rc) return rc;
+    double* dev = nullptr;   // mu | var | mean | bad | cov
+    if (hipMalloc((void**)&dev, sizeof(double) * (3 * (size_t)M + 2 + (size_t)M * M)) != hipSuccess) {
+        boss_cand_free(cd);
+        return fail(BOSS_E_ALLOC, "device allocation failed");
+    }
+    double *dmu = dev, *dvar = dev + M, *dmean = dev + 2 * (size_t)M;
+    unsigned long long* dbad = (unsigned long long*)(dev + 3 * (size_t)M);
+    double* dcov = dev + 3 * (size_t)M + 2;
+    hipStream_t s = c->stream;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(dev);
+        boss_cand_free(cd);
+    };
+    if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * M, hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(dbad, 0xff, sizeof(unsigned long long), s);
+    rc = predict_enqueue(g, cd, mean_Xs ? dmean : nullptr, dmu, dvar);   // leaves V in the slab scratch, Csc scaled
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    const int BN = (M >= 64 * 256) ? 64 : 32;
+    const int gb = (M + 15) / 16;
+    hipLaunchKernelGGL(predict_cov_kernel, dim3(gb, gb), dim3(256), 0, s, (const double*)c->vscratch.p, g->Np, BN,
+                       (const double*)c->csc.p, g->d, cd->Mp, M, g->kernel, g->amp2, dcov);
+    hipLaunchKernelGGL(clip_cov_diag_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dcov, M, dbad);
+    unsigned long long bad = 0;
+    (void)hipMemcpyAsync(mu, dmu, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(cov, dcov, sizeof(double) * (size_t)M * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (bad != ~0ULL) {
+        if (bad_index) *bad_index = (long)bad;
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "The posterior GP predicted variance %g but only values above -1e-08 are tolerated. (DomainError)", cov[bad * (size_t)M + bad]);
+        return fail(BOSS_E_NEG_VAR, msg);
+    }
+    return BOSS_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // acquisition
 // ------------------------------------------------------------------------------------------

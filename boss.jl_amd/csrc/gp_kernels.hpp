@@ -229,6 +229,49 @@ __global__ void predict_finalize_kernel(const double* __restrict__ ss, const dou
     var[j] = amp2 - ss[j] + PREDICT_JITTER;
 }
 
+// a5: full posterior covariance  Σ = K** − VᵀV + 1e-18·I  (mean_and_cov, gaussian_process.jl:180-184;
+// AbstractGPs cov(post(X*))) from the V slabs the prediction kernel left in its scratch
+// (V(n, j) = Vs[(j/BN * Np + n) * BN + j % BN]).  16×16 outputs per workgroup, n staged through LDS.
+// Not a hot path (EI never needs it); the diagonal is NOT clipped here (see clip_cov_diag_kernel).
+__global__ __launch_bounds__(256) void predict_cov_kernel(const double* __restrict__ Vs, int Np, int BN,
+                                                          const double* __restrict__ Csc, int d, int Mp, int M,
+                                                          int kern, double amp2, double* __restrict__ cov) {
+    __shared__ double Va[64][17], Vb[64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j1 = blockIdx.x * 16 + tx, j2 = blockIdx.y * 16 + ty;
+    double acc = 0.0;
+    for (int n0 = 0; n0 < Np; n0 += 64) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+            const int nn = idx >> 4, jj = idx & 15;
+            const int ja = blockIdx.x * 16 + jj, jb = blockIdx.y * 16 + jj;
+            Va[nn][jj] = (ja < M) ? Vs[((size_t)(ja / BN) * Np + n0 + nn) * BN + ja % BN] : 0.0;
+            Vb[nn][jj] = (jb < M) ? Vs[((size_t)(jb / BN) * Np + n0 + nn) * BN + jb % BN] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int nn = 0; nn < 64; ++nn) acc = __builtin_fma(Va[nn][tx], Vb[nn][ty], acc);
+    }
+    if (j1 < M && j2 < M) {
+        double r2 = 0.0;
+        for (int kd = 0; kd < d; ++kd) {
+            const double diff = Csc[(size_t)kd * Mp + j1] - Csc[(size_t)kd * Mp + j2];
+            r2 = __builtin_fma(diff, diff, r2);
+        }
+        cov[(size_t)j2 * M + j1] = amp2 * kappa_r2(kern, r2) - acc + ((j1 == j2) ? PREDICT_JITTER : 0.0);
+    }
+}
+
+// _clip_var on the diagonal of Σ (gaussian_process.jl:165,182)
+__global__ void clip_cov_diag_kernel(double* __restrict__ cov, int M, unsigned long long* __restrict__ bad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double v = cov[(size_t)j * M + j];
+    if (v >= 0.0) return;
+    if (v >= -MAX_NEG_VAR) cov[(size_t)j * M + j] = 0.0;
+    else atomicMin(bad, (unsigned long long)j);
+}
+
 // first index with var < -MAX_NEG_VAR  (DomainError of _clip_var); bad[0] initialised to LONG_MAX
 __global__ void clip_var_kernel(double* __restrict__ var, int M, unsigned long long* __restrict__ bad) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -17,10 +17,11 @@ from typing import Callable, Optional, Sequence
 
 import numpy as np
 
+from . import acquisition as acq_host
 from . import api
 from . import distributed as dist_util
 from .model import HipGaussianProcessPosterior
-from .problem import BossOptions, BossProblem, best_so_far, in_bounds, in_cons, in_domain
+from .problem import BossOptions, BossProblem, NonlinFitness, best_so_far, in_bounds, in_cons, in_domain
 
 
 def _rand_in_domain(x_prior: Callable, domain, rng, max_attempts: int):
@@ -40,7 +41,7 @@ def posteriors_of(problem: BossProblem):
 
 
 def acquisition_values(problem: BossProblem, posts: Sequence[HipGaussianProcessPosterior], Xs: np.ndarray,
-                       cand: Optional[api.Candidates] = None):
+                       cand: Optional[api.Candidates] = None, eps_seed: Optional[int] = 0):
     """vals = acq.(eachcol(xs)) for acq = construct_safe_acquisition(problem) — device-evaluated.
     Returns (acq[M], local argmax, local max)."""
     ei = problem.acquisition
@@ -53,6 +54,18 @@ def acquisition_values(problem: BossProblem, posts: Sequence[HipGaussianProcessP
     mask = None
     if ei.cons_safe:                                                   # make_safe (expected_improvement.jl:58-65)
         mask = in_bounds(Xs, problem.domain.bounds) & in_cons(Xs, problem.domain.cons)
+    if isinstance(ei.fitness, NonlinFitness):
+        # expected_improvement(::NonlinFitness) needs a user closure per Monte-Carlo sample: the device
+        # provides (μ, σ²) for every candidate / output / posterior sample, the ε-average runs on the host
+        if own:
+            cand.close()
+        mv = [p.mean_and_var(Xs) for p in posts]
+        rng = np.random.default_rng(eps_seed)
+        count = ei.eps_samples if len(posts) == 1 else len(posts)      # ϵ_sample_count (expected_improvement.jl:116-117)
+        eps = acq_host.sample_eps(problem.data.Y.shape[0], count, rng)
+        acq = acq_host.acquisition_nonlin(ei.fitness, mv, problem.y_max if constrained else None, b, eps, mask)
+        am = int(np.argmax(acq))
+        return acq, am, float(acq[am])
     gps = [[s.gp for s in p.slices] for p in posts]
     means = None
     m0 = posts[0].slices[0]._mean_s(Xs)

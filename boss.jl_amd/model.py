@@ -195,6 +195,14 @@ class HipGaussianProcessPosteriorSlice:
         mu, var = self.mean_and_var(x)
         return mu, np.sqrt(var)
 
+    def mean_and_cov(self, X):
+        """mean_and_cov(post, X::Matrix) (gaussian_process.jl:180-184) -> (mu[M], Σ[M,M])."""
+        X = np.asarray(X, float)
+        return self.gp.predict_cov(X, self._mean_s(X))
+
+    def cov(self, X):
+        return self.mean_and_cov(X)[1]
+
 
 @dataclass
 class HipGaussianProcessPosterior:
@@ -220,6 +228,14 @@ class HipGaussianProcessPosterior:
     def mean_and_std(self, x):
         mu, var = self.mean_and_var(x)
         return mu, np.sqrt(var)
+
+    def mean_and_cov(self, X):
+        """src/posterior.jl:74-79: means stacked as rows, covariances along dims=3 (M×M×P)."""
+        res = [s.mean_and_cov(X) for s in self.slices]
+        return np.vstack([r[0] for r in res]), np.stack([r[1] for r in res], axis=2)
+
+    def cov(self, X):
+        return self.mean_and_cov(X)[1]
 
 
 def average_mean(posts: Sequence[HipGaussianProcessPosterior], X):

@@ -144,8 +144,19 @@ class LinFitness:
 
 
 @dataclass
+class NonlinFitness:
+    """NonlinFitness(fitness::Function) (src/types/fitness.jl): a user closure y -> score."""
+    fitness: Callable
+
+    def __call__(self, y):
+        return float(self.fitness(np.asarray(y, float)))
+
+
+@dataclass
 class ExpectedImprovement:
-    fitness: LinFitness
+    """ExpectedImprovement(; fitness, ϵ_samples = 200, cons_safe = true) (expected_improvement.jl:39-45)."""
+    fitness: object
+    eps_samples: int = 200
     cons_safe: bool = True
 
 

@@ -114,6 +114,13 @@ int boss_gp_loglike_batch(int device, int kernel, int d, int N, const double* X,
 int boss_gp_predict(boss_gp_t* gp, int M, const double* Xs, const double* mean_Xs,
                     double* mu, double* var, long* bad_index);
 
+/* Replaces: mean_and_cov(post, X::Matrix) / cov (gaussian_process.jl:163-167,180-184):
+ *   Sigma = K** - V'V + 1e-18 I (M×M, column-major, full symmetric), diagonal through _clip_var.
+ * Not on the acquisition path (EI only needs the diagonal); provided so the whole posterior API
+ * of the plugin is served from the device-resident factor. */
+int boss_gp_predict_cov(boss_gp_t* gp, int M, const double* Xs, const double* mean_Xs,
+                        double* mu, double* cov, long* bad_index);
+
 /* resident candidates (one upload, many acquisition passes / many posteriors) */
 int boss_cand_create(int device, int d, int M, const double* Xs, boss_cand_t** out);
 void boss_cand_free(boss_cand_t* cand);

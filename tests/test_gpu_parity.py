@@ -331,3 +331,60 @@ def test_full_size_properties(api, O):
     mu, var = g.predict(X[:, :256])
     assert np.abs(mu - y[:256]).max() < 0.2 and np.all(var >= 0) and np.all(var < 0.05 ** 2 + 1e-6)
     g.close()
+
+
+def test_posterior_covariance(api, O):
+    """a5: mean_and_cov(post, X) (gaussian_process.jl:180-184) from the device-resident factor."""
+    X, y, Xs = make(3, 200, 37, seed=13)
+    lam = np.array([0.4, 0.5, 0.6])
+    ms = 0.2 * Xs.sum(0)
+    post = O.gp_fit(X, y, "matern52", lam, 1.1, 0.05, mean=0.2 * X.sum(0))
+    mu_o, S_o = O.gp_mean_and_cov(post, Xs, ms)
+    g = api.fit(X, y, "matern52", lam, 1.1, 0.05, 0.2 * X.sum(0))
+    mu, S = g.predict_cov(Xs, ms)
+    assert S.shape == (37, 37) and np.allclose(S, S.T, rtol=0, atol=1e-12)
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-9 * (1 + np.abs(mu_o).max()))
+    assert np.allclose(S, S_o, rtol=0, atol=1e-9 * 1.1 ** 2)
+    # diag(cov) == var (test/unit/test/models/gaussian_process.jl:119-120, atol 1e-8)
+    _, var = g.predict(Xs, ms)
+    assert np.allclose(np.diag(S), var, rtol=0, atol=1e-12)
+    # through the plugin mirror: P outputs -> M×M×P
+    import boss_jl_amd as B
+    model = B.HipGaussianProcess(lengthscale_priors=[None] * 2, amplitude_priors=[None] * 2, noise_std_priors=[None] * 2)
+    data = B.ExperimentData(X, np.stack([y, -y]))
+    params = B.HipGPParams(np.stack([lam, lam], axis=1), [1.1, 0.9], [0.05, 0.05])
+    pm = model.model_posterior(params, data)
+    mus, covs = pm.mean_and_cov(Xs[:, :5])
+    assert mus.shape == (2, 5) and covs.shape == (5, 5, 2)
+    assert np.allclose(covs[:, :, 0], O.gp_mean_and_cov(O.gp_fit(X, y, "matern52", lam, 1.1, 0.05), Xs[:, :5])[1], atol=1e-9)
+    g.close()
+
+
+def test_nonlinear_fitness_host_epilogue(api, O):
+    """a10: NonlinFitness EI = device (μ, σ²) + host Monte-Carlo average (expected_improvement.jl:104-111).
+    Reference orderings (test/unit/test/acquisitions/expected_improvement.jl:55-105, nonlin rows) and
+    agreement with the analytic LinFitness value for fit(y) = y[1]."""
+    import boss_jl_amd as B
+    from boss_jl_amd.maximizer import acquisition_values, posteriors_of
+    rng = np.random.default_rng(5)
+    d, N, M = 2, 60, 40
+    X = rng.uniform(0, 10, (d, N))
+    Y = np.stack([np.sin(X[0]) + 0.1 * X[1], 0.3 * X[0] - 1.0])
+    mk = lambda fit: B.BossProblem(f=None, domain=B.Domain(bounds=([0., 0.], [10., 10.])), y_max=[np.inf, 1.5],
+                                   acquisition=B.ExpectedImprovement(fit, eps_samples=4000),
+                                   model=B.HipGaussianProcess(lengthscale_priors=[None] * 2, amplitude_priors=[None] * 2,
+                                                              noise_std_priors=[None] * 2),
+                                   data=B.ExperimentData(X, Y),
+                                   params=B.HipGPParams(np.full((2, 2), 2.0), [1.0, 1.0], [0.05, 0.05]))
+    Xs = np.asfortranarray(rng.uniform(-1, 11, (d, M)))
+    p_lin, p_non = mk(B.LinFitness([1., 0.])), mk(B.NonlinFitness(lambda yy: yy[0]))
+    a_lin, am_lin, _ = acquisition_values(p_lin, posteriors_of(p_lin), Xs)
+    a_non, am_non, mx = acquisition_values(p_non, posteriors_of(p_non), Xs, eps_seed=1)
+    inb = O.in_bounds(Xs, [0., 0.], [10., 10.])
+    assert np.all(a_non[~inb] == 0.0) and np.all(a_non >= 0.0) and mx == a_non[am_non]
+    # Monte-Carlo (4000 ε) vs analytic: a few percent of the acquisition's scale
+    assert np.abs(a_non - a_lin).max() <= 0.05 * max(a_lin.max(), 1e-3) + 1e-4
+    # BI: one ε column per posterior sample
+    p_non.params = [p_non.params, B.HipGPParams(np.full((2, 2), 3.0), [1.2, 0.8], [0.05, 0.05])]
+    a_bi, _, _ = acquisition_values(p_non, posteriors_of(p_non), Xs, eps_seed=2)
+    assert a_bi.shape == (M,) and np.all(a_bi >= 0.0) and np.all(a_bi[~inb] == 0.0)
