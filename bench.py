@@ -114,18 +114,26 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (bosship has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; BOSS_BENCH_BACKEND=gloo lets the N>1 path be rehearsed on a 1-GPU box
+    # (all ranks then share device 0 and the exchange runs over gloo on CPU tensors)
+    backend = os.environ.get("BOSS_BENCH_BACKEND", "nccl")
+    n_vis = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < n_vis else local_rank % max(n_vis, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     entry.build()
     from boss_jl_amd import api
     from boss_jl_amd import distributed as dist_util
-    dev = local_rank
+    dev = dev_index
 
     X, y, Xs = problem(1 + 10 * rank)            # every rank: its own GP slice + its own candidate shard
     lam = np.full(D, 0.5)
@@ -133,13 +141,13 @@ def main():
     cand = api.Candidates(Xs, device=dev)
     best = float(y.max())
 
-    def step(i):
+    def step(i, exchange=True):
         t0 = time.perf_counter()
         # a different noise level each step so no step can reuse the previous factorisation
         gp.update(lam, 1.0, 0.05 + 1e-4 * (i % 7))
         t1 = time.perf_counter()
         _, am, mx = api.acq_ei([[gp]], cand, [1.0], None, best, want_acq=False)
-        if world > 1:
+        if world > 1 and exchange:
             mx, am = dist_util.argmax_exchange(mx, am + rank * M_CAND)
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1, am, mx
@@ -163,7 +171,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t_begin
 
-    times = torch.tensor([elapsed, t_upd, t_acq], dtype=torch.float64, device="cuda")
+    times = torch.tensor([elapsed, t_upd, t_acq], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, t_upd, t_acq = (float(v) for v in times.cpu())
@@ -175,7 +183,7 @@ def main():
         api.prof_reset(dev)
         reps = 3
         for i in range(reps):
-            step(i)
+            step(i, exchange=False)          # rank-0-only pass: must not contain a collective
         ms_pred, n_pred = api.prof_get(dev, "predict")
         ms_syrk, n_syrk = api.prof_get(dev, "potrf_syrk")
         ms_diag, n_diag = api.prof_get(dev, "potrf_diag")
