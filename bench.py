@@ -130,8 +130,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
-    entry.build()
+    if local_rank == 0:
+        entry.build()                    # one builder per node; the others wait, then just load the .so
+    if dist is not None:
+        dist.barrier()
     from boss_jl_amd import api
+    api.load_library()
     from boss_jl_amd import distributed as dist_util
     dev = dev_index
 
