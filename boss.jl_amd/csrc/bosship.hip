@@ -82,20 +82,13 @@ static int get_ctx(int device, Ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     {
-        // Side stream for the bulk trailing updates of the look-ahead Cholesky.  Its CU mask leaves
-        // every 4th CU free so that the (short, latency-critical) panel-chain kernels on the main
-        // stream always find an idle CU instead of queueing behind 128×128 syrk workgroups.
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, device));
-        const int ncu = prop.multiProcessorCount;
-        const int every = getenv("BOSS_CU_RESERVE_EVERY") ? atoi(getenv("BOSS_CU_RESERVE_EVERY")) : 0;   // measured: no gain from reserving CUs
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = 0; i < ncu; ++i)
-            if (every <= 1 || (i % every) != 0) mask[i / 32] |= (1u << (i % 32));
-        if (hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-        }
+        // Panel chain on the highest-priority stream, bulk trailing updates on the lowest-priority one.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        (void)hipStreamDestroy(c->own_stream);
+        HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest));
+        c->stream = c->own_stream;
+        HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     c->lookahead = !(getenv("BOSS_NO_LOOKAHEAD") && atoi(getenv("BOSS_NO_LOOKAHEAD")));
@@ -242,6 +235,15 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         }
         const int m = nblk - 1 - k;
         if (m == 0) break;
+        static const int small_m = getenv("BOSS_SMALL_M") ? atoi(getenv("BOSS_SMALL_M")) : 12;
+        if (la && m <= small_m) {
+            // few tiles left: one small single-stream launch beats the two-stream choreography
+            if (last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);
+            last_rest = -1;
+            hipLaunchKernelGGL(potrf_colupd_kernel, dim3(2 * m * (m + 1) + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
+                               m, m);
+            continue;
+        }
         if (!la) {
             ProfScope ps(c, "potrf_syrk");
             hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m * (m + 1) / 2 + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
@@ -251,16 +253,18 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         // ---- look-ahead: panel chain on `s`, bulk of the trailing update on the side stream ----------
         // the next panel's block column was last written by the side stream's update of step k-1
         if (last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);
-        hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, k, m);
+        hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, k, m, 1);
         last_rest = -1;
-        if (m >= 2) {
+        static const int exp_norest = getenv("BOSS_EXP_NOREST") ? atoi(getenv("BOSS_EXP_NOREST")) : 0;   // timing experiments only
+        if (m >= 2 && exp_norest != 1) {
             // the bulk update is released only AFTER the column update has been dispatched, so the two
             // do not fight for CUs; it then overlaps the next diagonal block + panel solve
             const int m2 = m - 1;                             // block triangle beyond the next panel
             (void)hipEventRecord(c->ev_panel[k], s);
             (void)hipStreamWaitEvent(c->side_stream, c->ev_panel[k], 0);
-            hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m2 * (m2 + 1) / 2 + m2, 1, batch), dim3(256), 0, c->side_stream, A,
-                               ld, bstride, k, k + 2, m2);
+            if (exp_norest != 2)
+                hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m2 * (m2 + 1) / 2 + m2, 1, batch), dim3(256), 0, c->side_stream, A,
+                                   ld, bstride, k, k + 2, m2);
             (void)hipEventRecord(c->ev_rest[k], c->side_stream);
             last_rest = k;
         }

@@ -359,12 +359,23 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
 }
 
 __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                              int m) {
-    // tiles: 4 per 128-row block of column k+1 (m blocks), then one 32-row tile of the δ^T rows
+                                                              int m, int ncols) {
+    // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
+    // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
+    // (used for the last steps, where one small launch beats the two-stream choreography).
     double* A = Abase + (size_t)blockIdx.z * bstride;
-    const int t = blockIdx.x;
-    const int R0 = (t < 4 * m) ? (k + 1) * BLK + t * 32 : (k + 1 + m) * BLK;
-    syrk_tile<RhsG>(A, ld, k, R0, (k + 1) * BLK);
+    int t = blockIdx.x;
+    int j = 0;
+    if (ncols > 1) {
+        // column j has 4*(m-j)+1 strips
+        while (t >= 4 * (m - j) + 1) {
+            t -= 4 * (m - j) + 1;
+            ++j;
+        }
+    }
+    const int nstr = 4 * (m - j);
+    const int R0 = (t < nstr) ? (k + 1 + j) * BLK + t * 32 : (k + 1 + m) * BLK;
+    syrk_tile<RhsG>(A, ld, k, R0, (k + 1 + j) * BLK);
 }
 
 // logdet = 2 Σ_{i<N} log L_ii ,  zz = Σ_{j<N} z_j²   →  scal[2*b], scal[2*b+1]
