@@ -388,3 +388,54 @@ def test_nonlinear_fitness_host_epilogue(api, O):
     p_non.params = [p_non.params, B.HipGPParams(np.full((2, 2), 3.0), [1.2, 0.8], [0.05, 0.05])]
     a_bi, _, _ = acquisition_values(p_non, posteriors_of(p_non), Xs, eps_seed=2)
     assert a_bi.shape == (M,) and np.all(a_bi >= 0.0) and np.all(a_bi[~inb] == 0.0)
+
+
+def test_domain_error_and_safe_acquisition(api, O):
+    """_clip_var's DomainError (gaussian_process.jl:186-194): predicting AT well-separated training
+    points with a huge amplitude and a tiny noise, the true variance (~σ²=1e-8) drowns in the rounding
+    error of α² − ‖v‖² (~eps·α² = 1e-6), so variances below −1e-8 appear.  boss_gp_predict reports
+    BOSS_E_NEG_VAR + the first offending index; the acquisition keeps going and marks those candidates
+    −Inf, as the reference's SafeFunction wrapper does (src/acquisition.jl:21-25)."""
+    X = np.arange(0.0, 400.0, 10.0)[None, :]
+    y = np.sin(X[0])
+    Xs = X.copy()
+    lam, amp, sig = [3.0], 1e5, 1e-4
+    post = O.gp_fit(X, y, "matern52", lam, amp, sig)
+    with pytest.raises(O.DomainError):
+        O.gp_mean_and_var(post, Xs)                  # the oracle (LAPACK) hits the same wall
+    g = api.fit(X, y, "matern52", lam, amp, sig)
+    with pytest.raises(api.DomainError) as e:
+        g.predict(Xs)
+    assert e.value.code == api.BOSS_E_NEG_VAR and 0 <= e.value.bad_index < Xs.shape[1]
+    acq, am, mx = api.acq_ei([[g]], api.Candidates(Xs), [1.0], None, float(y.max()))
+    assert np.isneginf(acq).any() and not np.isnan(acq).any()
+    assert acq[am] == mx and mx == np.max(acq)
+    # the unclipped device variances agree with the oracle's to the rounding level that causes the error
+    _, var_o = O.gp_mean_and_var(post, Xs, clip=False)
+    assert np.abs(var_o).max() < 1e-4
+
+
+def test_caller_stream(api, O):
+    """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
+    import torch
+    X, y, Xs = make(4, 300, 64, seed=2)
+    lam = np.full(4, 0.5)
+    want = O.gp_fit(X, y, "matern52", lam, 1.0, 0.05)
+    st = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(st):
+            api.set_stream(0, st.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g = api.GP(X, y, "matern52")
+            e0.record(st)
+            lp = g.update(lam, 1.0, 0.05)
+            mu, var = g.predict(Xs)
+            e1.record(st)
+            e1.synchronize()
+            assert e0.elapsed_time(e1) > 0.0
+    finally:
+        api.set_stream(0, None)
+    mu_o, var_o = O.gp_mean_and_var(want, Xs)
+    assert abs(lp - want.logpdf) <= 1e-9 * (1 + abs(want.logpdf))
+    assert np.allclose(mu, mu_o, atol=1e-9) and np.allclose(var, var_o, atol=1e-9)
+    g.close()
