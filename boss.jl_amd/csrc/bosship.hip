@@ -706,7 +706,9 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         g->have_dinv = true;
     }
     const int Mp = cd->Mp;
-    const int BN = (cd->M >= 64 * 256) ? 64 : 32;
+    // 64 candidates per workgroup once that still fills the machine (BOSS_FORCE_BN64=1: tests)
+    static const bool force64 = getenv("BOSS_FORCE_BN64") && atoi(getenv("BOSS_FORCE_BN64"));
+    const int BN = (cd->M >= 64 * 256 || force64) ? 64 : 32;
     const int tiles = (cd->M + BN - 1) / BN;
     int rc = ws_reserve(c->csc, sizeof(double) * (size_t)g->d * Mp);
     if (rc) return rc;
@@ -818,7 +820,8 @@ extern "C" int boss_gp_predict_cov(boss_gp_t* g, int M, const double* Xs, const 
         cleanup();
         return rc;
     }
-    const int BN = (M >= 64 * 256) ? 64 : 32;
+    static const bool force64 = getenv("BOSS_FORCE_BN64") && atoi(getenv("BOSS_FORCE_BN64"));
+    const int BN = (M >= 64 * 256 || force64) ? 64 : 32;     // must mirror predict_enqueue's choice (V slab layout)
     const int gb = (M + 15) / 16;
     hipLaunchKernelGGL(predict_cov_kernel, dim3(gb, gb), dim3(256), 0, s, (const double*)c->vscratch.p, g->Np, BN,
                        (const double*)c->csc.p, g->d, cd->Mp, M, g->kernel, g->amp2, dcov);

@@ -191,6 +191,17 @@ struct GemmNT {
 // register pressure, which collapses the prefetch distance) nor insert its own conservative
 // s_waitcnt; the waits are hand-counted (loads complete in order: waiting for vmcnt(n) retires
 // everything but the n most recent vector-memory operations).
+// REQUIREMENTS of the hand-counted scheme (each one was a real bug during bring-up):
+//   * uniform (scalar) control flow around the ring: under an EXEC-masked loop a fully masked-off
+//     wave still executes the instruction stream, its loads do not issue and do not bump vmcnt —
+//     the wave index is therefore taken through readfirstlane;
+//   * no register spills in kernels that use it (agpr_count == 0, no scratch): hipcc would copy a
+//     ring register before its load has landed (tests/test_abi_and_host.py checks the metadata).
+#ifdef BOSS_RING_PLAIN   // debugging aid: compiler-managed loads and waits
+__device__ __forceinline__ void gld16(v2d& dst, const double* p) { dst = *reinterpret_cast<const v2d*>(p); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {}
+#else
 __device__ __forceinline__ void gld16(v2d& dst, const double* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
@@ -199,6 +210,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+#endif
 
 template <int WR_, int WC_, int TM_, int TN_, int D_>
 struct GemmDirect {
@@ -218,7 +230,8 @@ struct GemmDirect {
     template <int SIGN>
     __device__ static __forceinline__ void run(const double* __restrict__ A, int lda, const double* __restrict__ B,
                                                int ldb, int K, v4d (&acc)[TM][TN]) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: uniform control flow around the ring
         const int wr = wave / WC, wc = wave % WC;
         const int aoff = wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda;   // per-lane element offsets
         const int boff = wc * (TN * 16) + 2 * (lane & 15) + (lane >> 4) * ldb;
@@ -282,7 +295,8 @@ struct GemmDirect {
     __device__ static __forceinline__ void run_Blds(const double* __restrict__ A, int lda,
                                                     const double* __restrict__ Bl, int ldbl, int K,
                                                     v4d (&acc)[TM][TN]) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: uniform control flow around the ring
         const int wr = wave / WC, wc = wave % WC;
         const int aoff = wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda;
         const double* Bs = Bl + wc * (TN * 16) + 2 * (lane & 15) + (lane >> 4) * ldbl;

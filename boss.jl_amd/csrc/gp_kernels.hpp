@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs
 template <class G>
 struct PredictLds {
     static constexpr int LDR = G::BN + 16;
-    static constexpr int BYTES = (BLK * LDR + 2 * G::WR * G::BN) * 8;
+    static constexpr int PART = 2 * G::TN * 4;       // per-thread Σv², v·z partials, parked in LDS between row blocks
+    static constexpr int BYTES = (BLK * LDR + 2 * G::WR * G::BN + G::NTHREADS * PART) * 8;
 };
 
 // G = GemmDirect<WR,1,TM,TN,D> with WR·TM·16 = 128: WR waves stacked along the 128 rows, BN = 16·TN candidates.
@@ -106,17 +107,19 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
     constexpr int BN = G::BN, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
     double* Rs = lds;
     double* red = Rs + BLK * LDR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar wave index (see gemm_f64.hpp)
     const int wr = wave, wc = 0;
     const int c0 = blockIdx.x * BN;
     double* V = Vscratch + (size_t)blockIdx.x * Np * BN;
     const int nblk = Np / BLK;
 
-    double ssp[TN][4], mzp[TN][4];
+    // per-thread partial sums live in LDS between row blocks (slot-major [slot][tid]: conflict-free).
+    // In registers they push the 64-candidate instantiation over 256 VGPRs; hipcc then spills to AGPRs
+    // and copies the inline-asm prefetch ring's registers BEFORE their loads have landed.
+    double* part = red + 2 * G::WR * G::BN;
 #pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ssp[n][i] = mzp[n][i] = 0.0;
+    for (int u = 0; u < 2 * TN * 4; ++u) part[u * G::NTHREADS + tid] = 0.0;
 
     for (int ib = 0; ib < nblk; ++ib) {
         v4d acc[TM][TN];
@@ -183,8 +186,9 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
                 for (int i = 0; i < 4; ++i) {
                     const double v = acc2[m][n][i];
                     if (!(dbg & 8)) V[(size_t)row * BN + G::col_of(wc, n, i, lane)] = v;
-                    ssp[n][i] = __builtin_fma(v, v, ssp[n][i]);
-                    mzp[n][i] = __builtin_fma(v, zr, mzp[n][i]);
+                    double* ps = part + (size_t)(2 * (n * 4 + i)) * G::NTHREADS + tid;
+                    ps[0] = __builtin_fma(v, v, ps[0]);
+                    ps[G::NTHREADS] = __builtin_fma(v, zr, ps[G::NTHREADS]);
                 }
         }
         __syncthreads();   // V_ib visible to the whole workgroup (it is the next block's B operand); Rs reusable
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
     for (int n = 0; n < TN; ++n)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            double s = ssp[n][i], z = mzp[n][i];
+            double s = part[(size_t)(2 * (n * 4 + i)) * G::NTHREADS + tid], z = part[(size_t)(2 * (n * 4 + i) + 1) * G::NTHREADS + tid];
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) {
                 s += __shfl_xor(s, off);

@@ -129,3 +129,22 @@ def test_shard_range_and_reduce_pairs():
     v, i = reduce_pairs([(1.0, 0), (float("nan"), 7), (5.0, 3)])
     assert i == 7 and v != v                                                   # NaN is the largest (Julia argmax)
     assert reduce_pairs([(-np.inf, 10), (-np.inf, 4)]) == (-np.inf, 4)
+
+
+def test_asm_ring_kernels_do_not_spill(tmp_path):
+    """The hand-counted prefetch ring (csrc/gemm_f64.hpp) is only correct if hipcc neither spills to
+    AGPRs nor to scratch in the kernels that use it (it would copy ring registers before their loads
+    have landed).  Checked on the code-object metadata, which cross-compiles without a GPU."""
+    import subprocess
+    out = tmp_path / "bosship.s"
+    flags = [f for f in entry.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags +
+                          ["-S", "--cuda-device-only", "-o", str(out), os.path.join(entry.CSRC, "bosship.hip")])
+    txt = out.read_text()
+    found = 0
+    for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", txt, re.S):
+        agpr, name, scratch, vgpr = int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(4))
+        if any(k in name for k in ("predict_kernel", "potrf_syrk", "potrf_colupd")):
+            found += 1
+            assert agpr == 0 and scratch == 0 and vgpr <= 256, (name, agpr, scratch, vgpr)
+    assert found >= 4

@@ -439,3 +439,31 @@ def test_caller_stream(api, O):
     assert abs(lp - want.logpdf) <= 1e-9 * (1 + abs(want.logpdf))
     assert np.allclose(mu, mu_o, atol=1e-9) and np.allclose(var, var_o, atol=1e-9)
     g.close()
+
+
+def test_64_candidate_instantiation():
+    """The 64-candidates-per-workgroup prediction kernel normally needs M >= 16384; BOSS_FORCE_BN64=1
+    selects it for any M (read once per process, hence the subprocess).  Covers GEMM1 + GEMM2 + covariance."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from boss_jl_amd import api
+from oracle import gp_oracle as O
+rng = np.random.default_rng(3)
+d, N, M = 3, 700, 150
+X = rng.uniform(0, 1, (d, N)); y = np.sin(2*np.pi*X).sum(0) + 0.05*rng.standard_normal(N)
+Xs = rng.uniform(0, 1, (d, M)); lam = np.full(d, 0.5)
+post = O.gp_fit(X, y, "matern52", lam, 1.0, 0.05)
+mu_o, S_o = O.gp_mean_and_cov(post, Xs)
+g = api.fit(X, y, "matern52", lam, 1.0, 0.05)
+mu, var = g.predict(Xs)
+mu2, S = g.predict_cov(Xs)
+assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, np.diag(S_o), rtol=0, atol=1e-9)
+assert np.allclose(S, S_o, rtol=0, atol=1e-9)
+print("ok64")
+''' % ROOT
+    env = dict(os.environ, BOSS_FORCE_BN64="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok64" in r.stdout, r.stdout + r.stderr
