@@ -47,6 +47,8 @@ SIGNATURES = {
     "boss_cand_free": (None, [C.c_void_p]),
     "boss_acq_ei": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, _c_dp, _c_dp, _c_dp, C.c_int,
                               C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_acq_ei_moments": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
+                                      C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
     "boss_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _c_dp]),
     "boss_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "boss_prof_reset": (C.c_int, [C.c_int]),
@@ -335,6 +337,29 @@ def acq_ei(gps: Sequence[Sequence[GP]], cand: Candidates, fit_coefs, y_max=None,
     _check(load_library().boss_acq_ei(P, S, arr, cand._h, _dp(ms), _dp(coefs), _dp(ym), 0 if best is None else 1,
                                       0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am),
                                       C.byref(mx)))
+    return acq, am.value, mx.value
+
+
+def acq_ei_moments(mu, var, fit_coefs, y_max=None, best=None, valid_mask=None, device: int = 0):
+    """EI·feas + arg-max from posterior moments already on the host (outputs fitted on other
+    ranks).  mu, var: [S][P][M] (or [P][M] for S = 1).  Returns (acq[M], argmax, max)."""
+    mu = np.asarray(mu, dtype=np.float64)
+    var = np.asarray(var, dtype=np.float64)
+    if mu.ndim == 2:
+        mu, var = mu[None], var[None]
+    S, P, M = mu.shape
+    assert var.shape == mu.shape
+    mu, var = np.ascontiguousarray(mu), np.ascontiguousarray(var)
+    coefs = _f64(np.asarray(fit_coefs).reshape(-1), 1)
+    assert coefs.shape[0] == P
+    ym = None if y_max is None else _f64(np.asarray(y_max).reshape(-1), 1)
+    mask = None if valid_mask is None else np.ascontiguousarray(np.asarray(valid_mask, dtype=bool).astype(np.uint8))
+    acq = np.zeros(M)
+    am = C.c_long(-1)
+    mx = C.c_double(0.0)
+    _check(load_library().boss_acq_ei_moments(device, P, S, M, _dp(mu), _dp(var), _dp(coefs), _dp(ym),
+                                              0 if best is None else 1, 0.0 if best is None else float(best),
+                                              _ucp(mask), _dp(acq), C.byref(am), C.byref(mx)))
     return acq, am.value, mx.value
 
 

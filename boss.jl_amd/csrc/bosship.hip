@@ -925,6 +925,56 @@ extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_
     return BOSS_OK;
 }
 
+// EI x feasibility from posterior moments that are already on the host (outputs fitted on other
+// ranks and all-gathered, SURVEY 8e "outputs"): the same K8/K9 epilogue kernels as boss_acq_ei.
+extern "C" int boss_acq_ei_moments(int device, int P, int S, int M, const double* mu, const double* var,
+                                   const double* fit_coefs, const double* y_max, int has_best, double best,
+                                   const unsigned char* valid_mask, double* acq_out, long* argmax_out,
+                                   double* max_out) {
+    if (P < 1 || S < 1 || M < 1 || !mu || !var || !fit_coefs) return fail(BOSS_E_INVALID, "bad arguments");
+    Ctx* c;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t pm = (size_t)P * M;
+    const size_t nd = 2 * pm * S + M + 2 * P + 4;
+    rc = ws_reserve(c->acq, sizeof(double) * nd + M);
+    if (rc) return rc;
+    double* dev = (double*)c->acq.p;
+    double* dmu = dev;
+    double* dvar = dmu + pm * S;
+    double* dacq = dvar + pm * S;
+    double* dcoef = dacq + M;
+    double* dymax = dcoef + P;
+    double* dval = dymax + P;
+    long* didx = (long*)(dval + 1);
+    unsigned char* dmask = (unsigned char*)(dev + nd);
+    (void)hipMemcpyAsync(dmu, mu, sizeof(double) * pm * S, hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(dvar, var, sizeof(double) * pm * S, hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(dcoef, fit_coefs, sizeof(double) * P, hipMemcpyHostToDevice, s);
+    if (y_max) (void)hipMemcpyAsync(dymax, y_max, sizeof(double) * P, hipMemcpyHostToDevice, s);
+    if (valid_mask) (void)hipMemcpyAsync(dmask, valid_mask, M, hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(dacq, 0, sizeof(double) * M, s);
+    const int mode = (has_best ? 1 : 0) | (y_max ? 2 : 0);
+    for (int sm = 0; sm < S; ++sm)
+        hipLaunchKernelGGL(ei_accumulate_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dmu + pm * sm, dvar + pm * sm, M,
+                           P, M, dcoef, y_max ? dymax : nullptr, mode, best, dacq);
+    hipLaunchKernelGGL(acq_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dacq, M, 1.0 / S,
+                       valid_mask ? dmask : nullptr);
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, s, dacq, M, dval, didx);
+    double hval = 0.0;
+    long hidx = -1;
+    (void)hipMemcpyAsync(&hval, dval, sizeof(double), hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&hidx, didx, sizeof(long), hipMemcpyDeviceToHost, s);
+    if (acq_out) (void)hipMemcpyAsync(acq_out, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (argmax_out) *argmax_out = hidx;
+    if (max_out) *max_out = hval;
+    return BOSS_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // measurement helpers
 // ------------------------------------------------------------------------------------------

@@ -1,7 +1,10 @@
 """One-process-per-GPU helpers (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU
 box, "gloo" in the CPU tests).  The hot path shards embarrassingly (candidates / outputs /
-hyper-parameter samples) so the only exchange is a 16-byte (value, index) all-gather
-for the arg-max — RCCL has no MAXLOC, so every rank reduces the gathered pairs locally."""
+hyper-parameter samples); the exchanges are all tiny and latency-bound:
+  candidates  one 16-byte (value, index) all-gather for the arg-max — RCCL has no MAXLOC, so
+              every rank reduces the gathered pairs locally;
+  outputs     one all-gather of the owners' (mu_i, var_i) rows (2·M·8 bytes per output);
+  samples     one all-reduce(sum) of the M partial acquisition sums."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -79,3 +82,51 @@ def allgather_concat(local: np.ndarray, group=None) -> np.ndarray:
     objs = [None] * d.get_world_size(group)
     d.all_gather_object(objs, np.asarray(local, dtype=np.float64), group=group)
     return np.concatenate(objs)
+
+
+def allreduce_sum(local: np.ndarray, group=None) -> np.ndarray:
+    """Element-wise sum over ranks of equally shaped float64 arrays (one all-reduce)."""
+    d = _dist()
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if d is None or d.get_world_size(group) == 1:
+        return local
+    import torch
+    t = torch.from_numpy(local.copy()).to(_device_for(d, group))
+    d.all_reduce(t, op=d.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+def owner_of(i: int, world: int) -> int:
+    """Output i (or any independent unit i) lives on rank i mod world."""
+    return i % world
+
+
+def allgather_owned(local_rows: dict, n_units: int, row_shape, group=None) -> np.ndarray:
+    """Every rank contributes the float64 rows it owns ({unit index: array of row_shape}, unit i
+    owned by rank i mod world); returns the full [n_units, *row_shape] array on every rank with
+    ONE fixed-size all-gather (ranks owning fewer units pad)."""
+    d = _dist()
+    row_shape = tuple(row_shape)
+    out = np.zeros((n_units,) + row_shape)
+    if d is None or d.get_world_size(group) == 1:
+        for i, r in local_rows.items():
+            out[i] = r
+        return out
+    import torch
+    rank, world = d.get_rank(group), d.get_world_size(group)
+    per = (n_units + world - 1) // world
+    buf = np.zeros((per,) + row_shape)
+    for i, r in local_rows.items():
+        assert owner_of(i, world) == rank
+        buf[i // world] = r
+    dev = _device_for(d, group)
+    mine = torch.from_numpy(buf).to(dev)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    d.all_gather(gathered, mine, group=group)
+    for r, t in enumerate(gathered):
+        a = t.cpu().numpy()
+        for slot in range(per):
+            i = slot * world + r
+            if i < n_units:
+                out[i] = a[slot]
+    return out

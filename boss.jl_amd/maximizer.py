@@ -6,9 +6,14 @@ points) with ONE device call for all candidates: posterior mean/variance for eve
 hyper-parameter sample, analytic EI × feasibility, make_safe mask, arg-max
 (construct_acquisition(::ExpectedImprovement), src/acquisitions/expected_improvement.jl:49-90).
 
-Multi-GPU (one process per GPU): every rank holds the (redundantly factorised) posterior,
-evaluates its contiguous shard of the candidates, and the per-rank (max, global index) pairs are
-combined with a single 16-byte all-gather over RCCL (distributed.py).
+Multi-GPU (one process per GPU), selected by `shard`:
+  "candidates"  every rank holds the (redundantly factorised) posterior and evaluates its
+                contiguous shard of the candidates; the per-rank (max, global index) pairs are
+                combined with a single 16-byte all-gather over RCCL;
+  "outputs"     output i is factorised and predicted on rank i mod G only; the (mu_i, var_i) rows
+                are all-gathered and the EI x feasibility epilogue + arg-max run from those moments;
+  "samples"     hyper-parameter sample s (BI) is factorised on its shard's rank only; the partial
+                sums of acq_s(x_j) are combined with one all-reduce(sum) of M doubles.
 """
 from __future__ import annotations
 
@@ -34,10 +39,42 @@ def _rand_in_domain(x_prior: Callable, domain, rng, max_attempts: int):
     return None
 
 
-def posteriors_of(problem: BossProblem):
-    """model_posterior(problem) (src/posterior.jl:2-3): list over BI samples of posteriors."""
-    post = problem.model.model_posterior(problem.params, problem.data)
+def posteriors_of(problem: BossProblem, lo: Optional[int] = None, hi: Optional[int] = None):
+    """model_posterior(problem) (src/posterior.jl:2-3): list over BI samples of posteriors.
+    [lo, hi) restricts the construction to a shard of the samples."""
+    params = problem.params
+    if lo is not None:
+        params = list(params)[lo:hi]
+        if not params:
+            return []
+    post = problem.model.model_posterior(params, problem.data)
     return post if isinstance(post, list) else [post]
+
+
+def n_samples(problem: BossProblem) -> int:
+    return len(problem.params) if isinstance(problem.params, (list, tuple)) else 1
+
+
+def output_moments(problem: BossProblem, i: int, Xs: np.ndarray) -> np.ndarray:
+    """(mu_i, var_i) of output i at all candidates for every hyper-parameter sample: [S][2][M].
+    Only the owner rank of output i factorises it (model_posterior_slice, gaussian_process.jl:133-141)."""
+    plist = list(problem.params) if isinstance(problem.params, (list, tuple)) else [problem.params]
+    out = np.empty((len(plist), 2, Xs.shape[1]))
+    for s, prm in enumerate(plist):
+        sl = problem.model.model_posterior_slice(prm, problem.data, i)
+        out[s, 0], out[s, 1] = sl.mean_and_var(Xs)
+        sl.gp.close()
+    return out
+
+
+def moments_acquisition(problem: BossProblem, mu: np.ndarray, var: np.ndarray, Xs: np.ndarray):
+    """EI x feasibility + arg-max on the device from gathered moments mu/var [S][P][M]."""
+    ei = problem.acquisition
+    b = best_so_far(ei.fitness, problem.data.Y, problem.y_max)
+    mask = None
+    if ei.cons_safe:
+        mask = in_bounds(Xs, problem.domain.bounds) & in_cons(Xs, problem.domain.cons)
+    return api.acq_ei_moments(mu, var, ei.fitness.coefs, problem.y_max, b, mask, problem.model.device)
 
 
 def acquisition_values(problem: BossProblem, posts: Sequence[HipGaussianProcessPosterior], Xs: np.ndarray,
@@ -87,6 +124,7 @@ class HipBatchAM:
     max_attempts: int = 200
     seed: Optional[int] = None
     group: object = None
+    shard: str = "candidates"           # "candidates" | "outputs" | "samples"
 
     def candidates(self, problem: BossProblem) -> np.ndarray:
         if self.points is not None:
@@ -103,6 +141,11 @@ class HipBatchAM:
         Xs = self.candidates(problem)                                   # identical on every rank (seeded)
         M = Xs.shape[1]
         rank, world = dist_util.rank_world(self.group)
+        if self.shard == "outputs":
+            return self._maximize_by_outputs(problem, Xs, rank, world, return_all)
+        if self.shard == "samples":
+            return self._maximize_by_samples(problem, Xs, rank, world, return_all)
+        assert self.shard == "candidates", self.shard
         lo, hi = dist_util.shard_range(M, rank, world)
         posts = posteriors_of(problem)
         if hi > lo:
@@ -114,3 +157,32 @@ class HipBatchAM:
             return Xs, (dist_util.allgather_concat(acq, self.group) if world > 1 else acq)
         mx, am = dist_util.argmax_exchange(mx, am, self.group)
         return Xs[:, am].copy(), mx
+
+    def _maximize_by_outputs(self, problem: BossProblem, Xs, rank, world, return_all):
+        if isinstance(problem.acquisition.fitness, NonlinFitness):
+            raise NotImplementedError("shard='outputs' needs the analytic EI of LinFitness; use shard='candidates'")
+        P, S, M = problem.data.Y.shape[0], n_samples(problem), Xs.shape[1]
+        mine = {i: output_moments(problem, i, Xs) for i in range(P) if dist_util.owner_of(i, world) == rank}
+        rows = dist_util.allgather_owned(mine, P, (S, 2, M), self.group)        # [P][S][2][M]
+        mu = np.ascontiguousarray(rows[:, :, 0, :].transpose(1, 0, 2))          # [S][P][M]
+        var = np.ascontiguousarray(rows[:, :, 1, :].transpose(1, 0, 2))
+        acq, am, mx = moments_acquisition(problem, mu, var, Xs)                  # identical on every rank
+        if return_all:
+            return Xs, acq
+        return Xs[:, am].copy(), mx
+
+    def _maximize_by_samples(self, problem: BossProblem, Xs, rank, world, return_all):
+        if isinstance(problem.acquisition.fitness, NonlinFitness):
+            raise NotImplementedError("shard='samples' needs the analytic EI of LinFitness; use shard='candidates'")
+        S, M = n_samples(problem), Xs.shape[1]
+        lo, hi = dist_util.shard_range(S, rank, world)
+        part = np.zeros(M)
+        if hi > lo:
+            posts = posteriors_of(problem, lo, hi)
+            acq, _, _ = acquisition_values(problem, posts, Xs)                   # mean over the local samples
+            part = acq * (hi - lo)
+        acq = dist_util.allreduce_sum(part, self.group) / S                      # (:87-90) mean over all samples
+        if return_all:
+            return Xs, acq
+        am = int(np.argmax(acq))                                                 # Julia argmax: first maximum, NaN largest
+        return Xs[:, am].copy(), float(acq[am])

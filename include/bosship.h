@@ -147,6 +147,17 @@ int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_t* cand,
                 int has_best, double best, const unsigned char* valid_mask,
                 double* acq_out, long* argmax_out, double* max_out);
 
+/* The same EI x feasibility epilogue (expected_improvement.jl:68-101,113-114) and arg-max, but
+ * from posterior moments the caller already holds: mu/var are S×P×M, index j + M*(p + P*s)
+ * (row p of sample s is what mean_and_var(post_s, Xs)[p, :] returns, src/posterior.jl:60-72).
+ * Used when the P outputs are fitted on different GPUs and their (mu, var) rows were all-gathered
+ * (one process per GPU; see boss.jl_amd/distributed.py).  var < -1e-8 poisons the candidate
+ * with -Inf as in boss_acq_ei. */
+int boss_acq_ei_moments(int device, int P, int S, int M, const double* mu, const double* var,
+                        const double* fit_coefs, const double* y_max, int has_best, double best,
+                        const unsigned char* valid_mask, double* acq_out, long* argmax_out,
+                        double* max_out);
+
 /* ---- measurement helpers (bench.py / profiles) ------------------------------------------ */
 /* issue-rate microbenchmark of v_mfma_f64_16x16x4_f64: every SIMD of the device issues
  * `iters` x 16 independent MFMAs; returns the achieved TFLOP/s (calibrates the fp64 MFMA peak

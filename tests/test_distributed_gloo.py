@@ -60,12 +60,81 @@ def _worker(rank, world, port, q):
         assert np.array_equal(x, Xs[:, j]) and val == full[j]
         _, allv = am.maximize_acquisition(problem=None, return_all=True)
         assert np.array_equal(allv, full)
+        _shard_modes(B, D, MX, O, rank, world)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, traceback.format_exc()))
     finally:
         dist.destroy_process_group()
+
+
+def _shard_modes(B, D, MX, O, rank, world):
+    """shard='samples' (all-reduce of partial sums) and shard='outputs' (all-gather of moment
+    rows): P = 3 outputs (ragged over 2 ranks), S = 5 samples (ragged), oracle-backed device calls."""
+    rng = np.random.default_rng(11)
+    d, N, M, P, S = 2, 25, 57, 3, 5
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), np.cos(2 * X).sum(0), X[0] - X[1]])
+    Xs = np.asfortranarray(rng.uniform(-0.1, 1.1, (d, M)))
+    y_max = np.array([np.inf, 1.5, 0.2])
+    coefs = [1.0, 0.5, 0.0]
+    prm = [B.HipGPParams(rng.uniform(0.3, 0.8, (d, P)), rng.uniform(0.8, 1.5, P), rng.uniform(0.03, 0.1, P)) for _ in range(S)]
+    model = B.HipGaussianProcess([None] * P, [None] * P, [None] * P)
+    dom = B.Domain((np.zeros(d), np.ones(d)))
+    prob = B.BossProblem(None, dom, B.ExpectedImprovement(B.LinFitness(coefs)), model, B.ExperimentData(X, Y), y_max, prm)
+
+    def opost(s, i):
+        return O.gp_fit(X, Y[i], "matern52", prm[s].lengthscales[:, i], prm[s].amplitudes[i], prm[s].noise_std[i])
+
+    all_posts = [[opost(s, i) for i in range(P)] for s in range(S)]
+    b = O.best_so_far(coefs, Y, y_max)
+    mask = O.in_bounds(Xs, np.zeros(d), np.ones(d))
+    full = O.ei_acquisition(all_posts, Xs, coefs, y_max, b, valid_mask=mask)
+    calls = {"posts": 0, "moments": []}
+
+    def fake_posteriors_of(problem, lo=None, hi=None):
+        calls["posts"] += 1
+        return all_posts[lo:hi]
+
+    def fake_acq(problem, posts, Xc, cand=None):
+        a = O.ei_acquisition(posts, Xc, coefs, y_max, b, valid_mask=mask)
+        j = int(np.argmax(a))
+        return a, j, float(a[j])
+
+    def fake_output_moments(problem, i, Xc):
+        calls["moments"].append(i)
+        return np.stack([np.stack(O.gp_mean_and_var(all_posts[s][i], Xc)) for s in range(S)])
+
+    def fake_moments_acq(problem, mu, var, Xc):
+        acc = np.zeros(Xc.shape[1])
+        for s in range(mu.shape[0]):
+            acc += O.expected_improvement_lin(coefs, mu[s], var[s], b) * O.feas_prob(mu[s], var[s], y_max)
+        a = np.where(mask, acc / mu.shape[0], 0.0)
+        j = int(np.argmax(a))
+        return a, j, float(a[j])
+
+    MX.posteriors_of, MX.acquisition_values = fake_posteriors_of, fake_acq
+    MX.output_moments, MX.moments_acquisition = fake_output_moments, fake_moments_acq
+    j = int(np.argmax(full))
+    # ---- samples: rank r factorises only its shard; one all-reduce(sum)
+    am = B.HipBatchAM(points=Xs, shard="samples")
+    x, val = am.maximize_acquisition(prob)
+    assert np.array_equal(x, Xs[:, j]) and abs(val - full[j]) <= 1e-15 * (1 + abs(full[j]))
+    _, allv = am.maximize_acquisition(prob, return_all=True)
+    assert np.allclose(allv, full, rtol=0, atol=1e-15)
+    # ---- outputs: rank r factorises outputs i = r mod world only; one all-gather of rows
+    am = B.HipBatchAM(points=Xs, shard="outputs")
+    x, val = am.maximize_acquisition(prob)
+    assert sorted(set(calls["moments"])) == [i for i in range(P) if i % world == rank]
+    assert np.array_equal(x, Xs[:, j]) and abs(val - full[j]) <= 1e-15 * (1 + abs(full[j]))
+    _, allv = am.maximize_acquisition(prob, return_all=True)
+    assert np.allclose(allv, full, rtol=0, atol=1e-15)
+    # ---- raw collectives
+    tot = D.allreduce_sum(np.arange(4.0) + rank)
+    assert np.array_equal(tot, world * np.arange(4.0) + sum(range(world)))
+    rows = D.allgather_owned({i: np.full((2,), float(i)) for i in range(5) if i % world == rank}, 5, (2,))
+    assert np.array_equal(rows, np.repeat(np.arange(5.0)[:, None], 2, axis=1))
 
 
 @pytest.mark.timeout(180)

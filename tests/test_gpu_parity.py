@@ -415,6 +415,49 @@ def test_domain_error_and_safe_acquisition(api, O):
     assert np.abs(var_o).max() < 1e-4
 
 
+def test_ei_from_moments_and_shard_modes(api, O):
+    """boss_acq_ei_moments (the EI x feas epilogue fed with gathered moments) and the three
+    sharding modes of HipBatchAM agree with the fused path and with the oracle."""
+    import boss_jl_amd as B
+    rng = np.random.default_rng(21)
+    d, N, M, P, S = 3, 90, 130, 2, 3
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), X[0] - X[1] + 0.3 * np.cos(5 * X[2])])
+    Xs = np.asfortranarray(rng.uniform(-0.1, 1.1, (d, M)))
+    y_max = np.array([np.inf, 0.4])
+    coefs = [1.0, 0.25]
+    prm = [B.HipGPParams(rng.uniform(0.3, 0.8, (d, P)), rng.uniform(0.8, 1.5, P), rng.uniform(0.03, 0.1, P)) for _ in range(S)]
+    model = B.HipGaussianProcess([None] * P, [None] * P, [None] * P)
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness(coefs)), model,
+                         B.ExperimentData(X, Y), y_max, prm)
+    oposts = [[O.gp_fit(X, Y[i], "matern52", p.lengthscales[:, i], p.amplitudes[i], p.noise_std[i]) for i in range(P)]
+              for p in prm]
+    b = O.best_so_far(coefs, Y, y_max)
+    mask = O.in_bounds(Xs, np.zeros(d), np.ones(d))
+    want = O.ei_acquisition(oposts, Xs, coefs, y_max, b, valid_mask=mask)
+    # moments entry point against the oracle's moments
+    mu = np.stack([np.stack([O.gp_mean_and_var(oposts[s][i], Xs)[0] for i in range(P)]) for s in range(S)])
+    var = np.stack([np.stack([O.gp_mean_and_var(oposts[s][i], Xs)[1] for i in range(P)]) for s in range(S)])
+    acq, am, mx = api.acq_ei_moments(mu, var, coefs, y_max, b, mask)
+    assert np.allclose(acq, want, rtol=0, atol=1e-13) and am == int(np.argmax(acq)) and mx == acq[am]
+    # poisoned variance -> -Inf for that candidate only
+    var2 = var.copy()
+    var2[1, 0, 7] = -1e-6
+    acq2, _, _ = api.acq_ei_moments(mu, var2, coefs, y_max, b, None)
+    assert acq2[7] == -np.inf and np.isfinite(np.delete(acq2, 7)).all()
+    # the three sharding modes (world size 1 here; world size 2 is covered by the gloo test)
+    res = {}
+    for mode in ("candidates", "outputs", "samples"):
+        am_ = B.HipBatchAM(points=Xs, shard=mode)
+        x, val = am_.maximize_acquisition(prob)
+        _, allv = am_.maximize_acquisition(prob, return_all=True)
+        assert np.allclose(allv, want, rtol=0, atol=1e-12), mode
+        res[mode] = (x, val)
+    j = int(np.argmax(want))
+    for mode, (x, val) in res.items():
+        assert np.array_equal(x, Xs[:, j]) and abs(val - want[j]) <= 1e-12, mode
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
