@@ -37,6 +37,7 @@ SIGNATURES = {
     "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
                               _c_ucp, C.POINTER(C.c_void_p), _c_dp]),
     "boss_gp_set_y": (C.c_int, [C.c_void_p, _c_dp]),
+    "boss_gp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_gp_free": (None, [C.c_void_p]),
     "boss_gp_get_factor": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
     "boss_gp_loglike_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
@@ -183,6 +184,29 @@ class GP:
     def set_y(self, y):
         y = _f64(np.asarray(y).reshape(-1), 1)
         _check(load_library().boss_gp_set_y(self._h, _dp(y)))
+
+    def append(self, X_new, y_new, mean_new=None) -> float:
+        """augment_dataset! + model_posterior with unchanged hyper-parameters (block Cholesky
+        append): X_new d×n (or a length-d vector), y_new n.  Returns the logpdf of all N+n points."""
+        X_new = _f64(X_new)
+        if X_new.ndim == 1:
+            X_new = _f64(X_new.reshape(-1, 1))
+        if X_new.shape[0] != self.d:
+            raise ValueError("X_new must be d×n")
+        n = X_new.shape[1]
+        y_new = _f64(np.asarray(y_new).reshape(-1), 1)
+        if y_new.shape[0] != n:
+            raise ValueError("y_new must have one entry per new point")
+        m = None if mean_new is None else _f64(np.asarray(mean_new).reshape(-1), 1)
+        if m is not None and m.shape[0] != n:
+            raise ValueError("mean_new must have one entry per new point")
+        out = C.c_double(0.0)
+        rc = load_library().boss_gp_append(self._h, n, _dp(X_new), _dp(y_new), _dp(m), C.byref(out))
+        if rc in (BOSS_OK, BOSS_E_NOT_PD):
+            self.N += n                      # the data were appended even if the factorisation failed
+        _check(rc)
+        self.logpdf = out.value
+        return out.value
 
     def factor(self):
         L = np.zeros((self.N, self.N), order="F")

@@ -231,7 +231,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         {
             ProfScope ps(c, "potrf_trsm");
             hipLaunchKernelGGL(potrf_trsm_kernel, dim3(nrows16, 1, batch), dim3(64), 0, s, A, ld, bstride, k, inv16,
-                               inv16_bstride);
+                               inv16_bstride, (k + 1) * BLK);
         }
         const int m = nblk - 1 - k;
         if (m == 0) break;
@@ -277,7 +277,7 @@ static void gram_enqueue(Ctx* c, const double* Xsc, size_t xs_bstride, int d, in
     ProfScope ps(c, "gram");
     const int nt = Np / 64;
     hipLaunchKernelGGL(gram_kernel, dim3(nt * (nt + 1) / 2, 1, batch), dim3(256), 0, c->stream, Xsc, xs_bstride, d, N,
-                       Np, kern, hyp, A, ld, bstride);
+                       Np, kern, hyp, A, ld, bstride, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -413,6 +413,31 @@ static int gp_finish(boss_gp* g, double* logpdf_out) {
     return BOSS_OK;
 }
 
+// Gram + blocked Cholesky + solves + logdet of the handle's resident data under its resident
+// hyper-parameters; results land in host_res when the stream drains.
+static int factor_enqueue(boss_gp* g) {
+    Ctx* c = g->ctx;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
+    {
+        ProfScope ps(c, "prep");
+        hipLaunchKernelGGL(scale_points_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc,
+                           (size_t)0, g->invlam, g->d, g->Np);
+        hipLaunchKernelGGL(rhs_rows_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0,
+                           g->N, g->Np, g->y, g->mean, (size_t)0, 0);
+    }
+    gram_enqueue(c, g->Xsc, 0, g->d, g->N, g->Np, g->kernel, g->hyp, g->A, g->ld, 0, 1);
+    potrf_enqueue(c, g->A, g->ld, g->Np, 1, 0, g->inv16, 0, g->info);
+    {
+        ProfScope ps(c, "logdet");
+        hipLaunchKernelGGL(potrf_logdet_kernel, dim3(1, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0, g->N, g->Np,
+                           g->scal);
+    }
+    HIPCHK(hipMemcpyAsync(g->host_res, g->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&g->host_res[2], g->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    return BOSS_OK;
+}
+
 extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double amplitude, double noise_std,
                               const double* mean_X, int flags, double* logpdf_out) {
     if (!g) return fail(BOSS_E_INVALID, "gp is NULL");
@@ -443,23 +468,8 @@ extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double am
         HIPCHK(hipMemsetAsync(g->mean, 0, sizeof(double) * g->Np, s));
         g->has_mean = false;
     }
-    HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
-    {
-        ProfScope ps(c, "prep");
-        hipLaunchKernelGGL(scale_points_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc,
-                           (size_t)0, g->invlam, g->d, g->Np);
-        hipLaunchKernelGGL(rhs_rows_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0,
-                           g->N, g->Np, g->y, g->mean, (size_t)0);
-    }
-    gram_enqueue(c, g->Xsc, 0, g->d, g->N, g->Np, g->kernel, g->hyp, g->A, g->ld, 0, 1);
-    potrf_enqueue(c, g->A, g->ld, g->Np, 1, 0, g->inv16, 0, g->info);
-    {
-        ProfScope ps(c, "logdet");
-        hipLaunchKernelGGL(potrf_logdet_kernel, dim3(1, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0, g->N, g->Np,
-                           g->scal);
-    }
-    HIPCHK(hipMemcpyAsync(g->host_res, g->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&g->host_res[2], g->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    rc = factor_enqueue(g);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     g->pending = true;
     if (flags & BOSS_FIT_NO_SYNC) return BOSS_OK;
@@ -474,6 +484,115 @@ extern "C" int boss_gp_sync(boss_gp_t* g, double* logpdf_out) {
         if (logpdf_out) *logpdf_out = -0.5 * (g->N * 1.8378770664093453 + g->host_res[0] + g->host_res[1]);
         return BOSS_OK;
     }
+    return gp_finish(g, logpdf_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// block Cholesky append: augment_dataset! + model_posterior with unchanged
+// hyper-parameters.  Only the block rows that contain new observations are (re)built: their
+// Gram rows are swept through the finished panels 0..kb-1 (solve with L_kk, rank-128 update of
+// the rest of the block row and of its δ^T entries), then the diagonal block is factorised like
+// any other — the right-looking factorisation restricted to one block row, O(N²) per 128 rows.
+// ------------------------------------------------------------------------------------------
+static int gp_grow(boss_gp* g, int Nnew) {
+    const int Np2 = round_up(Nnew, BLK);
+    if (Np2 <= g->Np) return BOSS_OK;
+    Ctx* c = g->ctx;
+    hipStream_t s = c->stream;
+    const int Np = g->Np, d = g->d, nblk2 = Np2 / BLK, ld2 = Np2 + RHS_ROWS;
+    const size_t szA = sizeof(double) * (size_t)ld2 * Np2;
+    double* nw[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[7] = {sizeof(double) * d * Np2, sizeof(double) * d * Np2, sizeof(double) * Np2, sizeof(double) * Np2,
+                             szA, sizeof(double) * nblk2 * 8 * 256, sizeof(double) * nblk2 * BLK * BLK};
+    for (int i = 0; i < 7; ++i)
+        if (hipMalloc((void**)&nw[i], bytes[i]) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipFree(nw[j]);
+            return fail(BOSS_E_ALLOC, "device allocation failed while growing the posterior handle");
+        }
+    for (int i = 0; i < 5; ++i) HIPCHK(hipMemsetAsync(nw[i], 0, bytes[i], s));
+    HIPCHK(hipMemcpy2DAsync(nw[0], sizeof(double) * Np2, g->Xraw, sizeof(double) * Np, sizeof(double) * Np, d,
+                            hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpy2DAsync(nw[1], sizeof(double) * Np2, g->Xsc, sizeof(double) * Np, sizeof(double) * Np, d,
+                            hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(nw[2], g->y, sizeof(double) * Np, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(nw[3], g->mean, sizeof(double) * Np, hipMemcpyDeviceToDevice, s));
+    // factor: rows 0..Np-1 of every old column; the δ^T / z row block moves from row Np to row Np2
+    HIPCHK(hipMemcpy2DAsync(nw[4], sizeof(double) * ld2, g->A, sizeof(double) * g->ld, sizeof(double) * Np, Np,
+                            hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpy2DAsync(nw[4] + Np2, sizeof(double) * ld2, g->A + Np, sizeof(double) * g->ld,
+                            sizeof(double) * RHS_ROWS, Np, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(nw[5], g->inv16, sizeof(double) * g->nblk * 8 * 256, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double* old[7] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv};
+    for (double* p : old) (void)hipFree(p);
+    g->Xraw = nw[0]; g->Xsc = nw[1]; g->y = nw[2]; g->mean = nw[3]; g->A = nw[4]; g->inv16 = nw[5]; g->Dinv = nw[6];
+    g->Np = Np2;
+    g->nblk = nblk2;
+    g->ld = ld2;
+    g->have_dinv = false;
+    return BOSS_OK;
+}
+
+extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const double* y_new, const double* mean_new,
+                              double* logpdf_out) {
+    if (!g || n < 1 || !X_new || !y_new) return fail(BOSS_E_INVALID, "need a handle, n >= 1 and non-NULL X_new, y_new");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (g->pending) {
+        int rc0 = gp_finish(g, nullptr);
+        if (rc0) return rc0;
+    }
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "append needs a fitted handle (its hyper-parameters are reused)");
+    hipStream_t s = c->stream;
+    const int d = g->d, N0 = g->N, N1 = N0 + n;
+    int rc = gp_grow(g, N1);
+    if (rc) return rc;
+    g->fitted = false;
+    g->have_dinv = false;
+    {
+        std::vector<double> xb;
+        pack_points(xb, X_new, d, n, n, g->discrete.empty() ? nullptr : g->discrete.data());
+        HIPCHK(hipMemcpy2DAsync(g->Xraw + N0, sizeof(double) * g->Np, xb.data(), sizeof(double) * n, sizeof(double) * n, d,
+                                hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(g->y + N0, y_new, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        if (mean_new) {
+            HIPCHK(hipMemcpyAsync(g->mean + N0, mean_new, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            g->has_mean = true;
+        }
+        HIPCHK(hipStreamSynchronize(s));       // staging buffers go out of scope
+    }
+    g->N = N1;
+    const int kb0 = N0 / BLK, kb1 = (N1 - 1) / BLK;
+    if (kb1 - kb0 + 1 > 4 || kb1 - kb0 + 1 >= g->nblk) {
+        // most of the matrix is new: a plain re-factorisation is cheaper than block-row sweeps
+        rc = factor_enqueue(g);
+        if (rc) return rc;
+    } else {
+        const int Np = g->Np, ld = g->ld;
+        HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
+        hipLaunchKernelGGL(scale_points_kernel, dim3((Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc, (size_t)0,
+                           g->invlam, d, Np);
+        for (int kb = kb0; kb <= kb1; ++kb) {
+            hipLaunchKernelGGL(rhs_rows_kernel, dim3(1, 1, 1), dim3(BLK), 0, s, g->A, ld, (size_t)0, N1, Np, g->y, g->mean,
+                               (size_t)0, kb * BLK);
+            hipLaunchKernelGGL(gram_kernel, dim3(4 * kb + 3, 1, 1), dim3(256), 0, s, g->Xsc, (size_t)0, d, N1, Np, g->kernel,
+                               g->hyp, g->A, ld, (size_t)0, kb * (2 * kb + 1));
+            for (int k = 0; k < kb; ++k) {
+                hipLaunchKernelGGL(potrf_trsm_kernel, dim3(8, 1, 1), dim3(64), 0, s, g->A, ld, (size_t)0, k, g->inv16, (size_t)0,
+                                   kb * BLK);
+                hipLaunchKernelGGL(potrf_rowupd_kernel, dim3(4 * (kb - k) + 1), dim3(256), 0, s, g->A, ld, k, kb, Np);
+            }
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, 1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, g->A, ld, (size_t)0, kb,
+                               g->inv16, (size_t)0, g->info);
+            hipLaunchKernelGGL(potrf_trsm_kernel, dim3(1, 1, 1), dim3(64), 0, s, g->A, ld, (size_t)0, kb, g->inv16, (size_t)0,
+                               Np);
+        }
+        hipLaunchKernelGGL(potrf_logdet_kernel, dim3(1, 1, 1), dim3(256), 0, s, g->A, ld, (size_t)0, N1, Np, g->scal);
+        HIPCHK(hipMemcpyAsync(g->host_res, g->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&g->host_res[2], g->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipGetLastError());
+    g->pending = true;
     return gp_finish(g, logpdf_out);
 }
 
@@ -612,7 +731,7 @@ extern "C" int boss_gp_loglike_batch(int device, int kernel, int d, int N, const
             hipLaunchKernelGGL(scale_points_kernel, dim3((Np + 255) / 256, 1, nb), dim3(256), 0, s, Xraw, Xsc, xs_bstride,
                                invlam, d, Np);
             hipLaunchKernelGGL(rhs_rows_kernel, dim3((Np + 255) / 256, 1, nb), dim3(256), 0, s, A, ld, bstride, N, Np,
-                               ydev, mean_arg, mean_b);
+                               ydev, mean_arg, mean_b, 0);
         }
         gram_enqueue(c, Xsc, xs_bstride, d, N, Np, kernel, hyp, A, ld, bstride, nb);
         potrf_enqueue(c, A, ld, Np, nb, bstride, inv16, inv16_b, info);

@@ -19,10 +19,13 @@ __global__ void scale_points_kernel(const double* __restrict__ Xraw, double* __r
 }
 
 // RHS row block: row Np = (y - m)^T for j < N, everything else in rows Np..Np+31 zero.
+// col0: first column to (re)write — 0 for a full fit, the first column of the re-factorised block
+// row for boss_gp_append (the z entries of the columns before it are final and must survive).
 __global__ void rhs_rows_kernel(double* __restrict__ Abase, int ld, size_t bstride, int N, int Np,
-                                const double* __restrict__ y, const double* __restrict__ mean, size_t mean_bstride) {
+                                const double* __restrict__ y, const double* __restrict__ mean, size_t mean_bstride,
+                                int col0) {
     const int b = blockIdx.z;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = col0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Np) return;
     double* col = Abase + (size_t)b * bstride + (size_t)j * ld + Np;
     double m = mean ? mean[(size_t)b * mean_bstride + j] : 0.0;
@@ -35,10 +38,12 @@ __global__ void rhs_rows_kernel(double* __restrict__ Abase, int ld, size_t bstri
 // hyp[b] = {α², σ²}.
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xsc, size_t xs_bstride, int d, int N,
                                                    int Np, int kern, const double* __restrict__ hyp,
-                                                   double* __restrict__ Abase, int ld, size_t bstride) {
+                                                   double* __restrict__ Abase, int ld, size_t bstride, int tile0) {
+    // tile0: first tile of the row-major enumeration of the lower 64×64 tile triangle (0 = whole
+    // matrix; T(2kb) = kb(2kb+1) starts block row kb, which boss_gp_append rebuilds alone)
     __shared__ double xj[16][64];
     const int b = blockIdx.z, tid = threadIdx.x;
-    const int t = blockIdx.x;
+    const int t = tile0 + blockIdx.x;
     int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
     while (bi * (bi + 1) / 2 > t) --bi;

@@ -250,12 +250,14 @@ __device__ __forceinline__ void wave_trsm16(const double* __restrict__ Lkk, int 
 
 __global__ __launch_bounds__(64) void potrf_trsm_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
                                                         const double* __restrict__ inv16base,
-                                                        size_t inv16_bstride) {
+                                                        size_t inv16_bstride, int row0) {
+    // row0: first row solved by 16-row group 0 — (k+1)*BLK in the factorisation (everything below
+    // the diagonal block); boss_gp_append solves only the block row it rebuilds, or only the δ^T rows
     const int lane = threadIdx.x;
     double* A = Abase + (size_t)blockIdx.z * bstride;
     const double* Lkk = A + (size_t)k * BLK * ((size_t)ld + 1);
     const double* inv16k = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
-    double* Brow = A + (size_t)(k + 1) * BLK + (size_t)blockIdx.x * 16 + (size_t)k * BLK * ld;
+    double* Brow = A + (size_t)row0 + (size_t)blockIdx.x * 16 + (size_t)k * BLK * ld;
     v4d acc[8];
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb)
@@ -376,6 +378,16 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     const int nstr = 4 * (m - j);
     const int R0 = (t < nstr) ? (k + 1 + j) * BLK + t * 32 : (k + 1 + m) * BLK;
     syrk_tile<RhsG>(A, ld, k, R0, (k + 1 + j) * BLK);
+}
+
+// Block-row variant for boss_gp_append: behind panel k update ONLY block row kb (4 strips of
+// 32×128 per column block k+1..kb, the last one being the diagonal block of the rebuilt rows) and
+// the δ^T entries of block column kb:  C_{kb,c} -= W_k L_ck^T ,  δ^T_kb -= z_k W_k^T.
+__global__ __launch_bounds__(256, 2) void potrf_rowupd_kernel(double* __restrict__ A, int ld, int k, int kb, int Np) {
+    const int t = blockIdx.x;
+    const int nstr = 4 * (kb - k);
+    if (t < nstr) syrk_tile<RhsG>(A, ld, k, kb * BLK + (t & 3) * 32, (k + 1 + (t >> 2)) * BLK);
+    else syrk_tile<RhsG>(A, ld, k, Np, kb * BLK);
 }
 
 // logdet = 2 Σ_{i<N} log L_ii ,  zz = Σ_{j<N} z_j²   →  scal[2*b], scal[2*b+1]

@@ -136,8 +136,11 @@ class HipBatchAM:
             raise RuntimeError("HipBatchAM: No samples were successfully drawn! Check the `x_prior` and the `Domain`.")
         return np.asfortranarray(np.stack(xs, axis=1))
 
-    def maximize_acquisition(self, problem: BossProblem, options: BossOptions = BossOptions(), return_all: bool = False):
-        """maximize_acquisition(::SamplingAM, problem, options) (sampling.jl:20-40) -> (x, val)."""
+    def maximize_acquisition(self, problem: BossProblem, options: BossOptions = BossOptions(), return_all: bool = False,
+                             posts=None):
+        """maximize_acquisition(::SamplingAM, problem, options) (sampling.jl:20-40) -> (x, val).
+        posts: already-built posteriors of `problem` (HipSequentialBatchAM keeps them resident and
+        extends them by block Cholesky appends); default: build them from problem.params."""
         Xs = self.candidates(problem)                                   # identical on every rank (seeded)
         M = Xs.shape[1]
         rank, world = dist_util.rank_world(self.group)
@@ -147,7 +150,8 @@ class HipBatchAM:
             return self._maximize_by_samples(problem, Xs, rank, world, return_all)
         assert self.shard == "candidates", self.shard
         lo, hi = dist_util.shard_range(M, rank, world)
-        posts = posteriors_of(problem)
+        if posts is None:
+            posts = posteriors_of(problem)
         if hi > lo:
             acq, am, mx = acquisition_values(problem, posts, Xs[:, lo:hi])
             am += lo
@@ -158,6 +162,7 @@ class HipBatchAM:
         mx, am = dist_util.argmax_exchange(mx, am, self.group)
         return Xs[:, am].copy(), mx
 
+    # (the two modes below factorise only a shard of the outputs / samples on each rank)
     def _maximize_by_outputs(self, problem: BossProblem, Xs, rank, world, return_all):
         if isinstance(problem.acquisition.fitness, NonlinFitness):
             raise NotImplementedError("shard='outputs' needs the analytic EI of LinFitness; use shard='candidates'")
@@ -186,3 +191,35 @@ class HipBatchAM:
             return Xs, acq
         am = int(np.argmax(acq))                                                 # Julia argmax: first maximum, NaN largest
         return Xs[:, am].copy(), float(acq[am])
+
+
+@dataclass
+class HipSequentialBatchAM:
+    """SequentialBatchAM(am, batch_size) (src/acquisition_maximizers/batch.jl:18-38): select
+    `batch_size` candidates one after the other, augmenting a COPY of the problem with the
+    'speculative' observation (x, posterior mean at x) after each selection.
+
+    The reference rebuilds the posterior from scratch (an O(N^3) Cholesky) for every selected
+    point; here the posteriors stay resident and each speculative observation is a block Cholesky
+    append (boss_gp_append, O(N^2)) under the unchanged hyper-parameters — same posterior."""
+    am: HipBatchAM
+    batch_size: int
+
+    def maximize_acquisition(self, problem: BossProblem, options: BossOptions = BossOptions()):
+        import copy
+        prob = copy.copy(problem)                                        # problem_ = deepcopy(problem) (batch.jl:27)
+        prob.data = type(problem.data)(problem.data.X.copy(), problem.data.Y.copy())
+        posts = posteriors_of(prob)
+        xs = []
+        try:
+            for _ in range(self.batch_size):                             # speculative_evaluation! (batch.jl:32-38)
+                x, _ = self.am.maximize_acquisition(prob, options, posts=posts)
+                y = sum(p.mean(x) for p in posts) / len(posts)           # mean(post, x); BI: average_mean
+                prob.augment_dataset(x, y)
+                for p in posts:
+                    p.append(x, y)
+                xs.append(x)
+        finally:
+            for p in posts:
+                p.close()
+        return np.stack(xs, axis=1), None

@@ -203,6 +203,16 @@ class HipGaussianProcessPosteriorSlice:
     def cov(self, X):
         return self.mean_and_cov(X)[1]
 
+    def append(self, x, y_i: float) -> float:
+        """Posterior of the data augmented by (x, y_i) under the same hyper-parameters — what
+        model_posterior returns after augment_dataset! (problem.jl:191-198) — as a block Cholesky
+        append on the resident factor (boss_gp_append).  x: length-d vector or d×n matrix."""
+        x = np.asarray(x, float)
+        return self.gp.append(x, y_i, self._mean_s(x))
+
+    def close(self):
+        self.gp.close()
+
 
 @dataclass
 class HipGaussianProcessPosterior:
@@ -236,6 +246,16 @@ class HipGaussianProcessPosterior:
 
     def cov(self, X):
         return self.mean_and_cov(X)[1]
+
+    def append(self, x, y):
+        """Append one observation (x, y[P]) (or n of them: x d×n, y P×n) to every output slice."""
+        y = np.asarray(y, float)
+        for i, s in enumerate(self.slices):
+            s.append(x, y[i])
+
+    def close(self):
+        for s in self.slices:
+            s.close()
 
 
 def average_mean(posts: Sequence[HipGaussianProcessPosterior], X):

@@ -87,6 +87,18 @@ int boss_gp_fit(int device, int kernel, int d, int N, const double* X, const dou
                 const unsigned char* discrete, boss_gp_t** out, double* logpdf_out);
 /* append-free refresh of the observations of a resident handle (same N): y only. */
 int boss_gp_set_y(boss_gp_t* gp, const double* y);
+/* Block Cholesky append.  Replaces: augment_dataset!(problem, x, y)
+ * (src/types/problem.jl:191-198) followed by the model_posterior(problem) that
+ * SequentialBatchAM's speculative loop recomputes from scratch for every selected point
+ * (src/acquisition_maximizers/batch.jl:26-38), i.e. posterior_gp (gaussian_process.jl:199-211)
+ * on the augmented data with the SAME hyper-parameters as the last boss_gp_update.
+ * X_new is d×n column-major, y_new has n entries, mean_new is the prior mean at the new points
+ * (n entries, or NULL for zero).  Only the 128-row blocks that contain new observations are
+ * rebuilt (O(N^2) work per block instead of the O(N^3) re-factorisation); the result — factor,
+ * z = L^{-1}(y-m), logpdf of all N+n observations — equals a fresh fit of the augmented data
+ * to rounding.  The handle must be fitted; device storage grows as needed. */
+int boss_gp_append(boss_gp_t* gp, int n, const double* X_new, const double* y_new, const double* mean_new,
+                   double* logpdf_out);
 void boss_gp_free(boss_gp_t* gp);
 
 /* introspection for parity tests: lower Cholesky factor L (N×N column-major, upper part zeroed)

@@ -73,6 +73,33 @@ def timing(d=8, N=4096, M=8192):
     api.prof_enable(0, False)
 
 
+def append_timing(d=8, N=4096, steps=12):
+    """SequentialBatchAM-style speculative loop: one point appended per step (block Cholesky
+    append) against a fresh factorisation of the same augmented data."""
+    X, y, Xs = problem(d, N + steps, 256)
+    lam = np.full(d, 0.5)
+    g = api.GP(X[:, :N], y[:N], "matern52")
+    g.update(lam, 1.0, 0.05)
+    ts = []
+    for i in range(steps):
+        t = time.time()
+        lp = g.append(X[:, N + i], y[N + i])
+        ts.append(time.time() - t)
+    mu, var = g.predict(Xs)
+    g2 = api.GP(X, y, "matern52")
+    g2.update(lam, 1.0, 0.05)
+    t = time.time()
+    lp2 = g2.update(lam, 1.0, 0.05)
+    t_full = time.time() - t
+    mu2, var2 = g2.predict(Xs)
+    print(f"append N={N}+1 x{steps}: first (grows storage) {ts[0]*1e3:.3f} ms, then {np.median(ts[1:])*1e3:.3f} ms/append "
+          f"vs full refit {t_full*1e3:.3f} ms;  |dlogpdf|={abs(lp-lp2):.2e} |dmu|={np.abs(mu-mu2).max():.2e} "
+          f"|dvar|={np.abs(var-var2).max():.2e}", flush=True)
+    t = time.time()
+    lp = g.append(X[:, :64] + 1e-3, y[:64])
+    print(f"append 64 points at once: {(time.time()-t)*1e3:.3f} ms", flush=True)
+
+
 def batch_cfg(S=512, N=1024, d=8):
     """BASELINE config 5: S hyper-parameter sets, each its own N=1024 Cholesky."""
     X, y, _ = problem(d, N, 1, seed=4)
@@ -132,6 +159,8 @@ if __name__ == "__main__":
         parity(8, 4096, 512)
     if "timing" in stages:
         timing()
+    if "append" in stages:
+        append_timing()
     if "batch" in stages:
         batch_cfg()
     if "multi" in stages:

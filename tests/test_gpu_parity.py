@@ -458,6 +458,108 @@ def test_ei_from_moments_and_shard_modes(api, O):
         assert np.array_equal(x, Xs[:, j]) and abs(val - want[j]) <= 1e-12, mode
 
 
+@pytest.mark.parametrize("N0,steps", [(5, [1, 1, 3]), (100, [1]), (127, [2]), (128, [1]), (130, [1, 1, 1]), (255, [1, 130]),
+                                      (300, [40, 100]), (256, [600]), (640, [1, 1])])
+def test_block_cholesky_append(api, O, N0, steps):
+    """boss_gp_append == a fresh fit of the augmented data (augment_dataset! + model_posterior with
+    unchanged hyper-parameters, problem.jl:191-198 / batch.jl:32-38): logpdf, factor, mean, variance."""
+    rng = np.random.default_rng(N0 + 7 * len(steps))
+    d, M = 3, 41
+    Ntot = N0 + sum(steps)
+    X = rng.uniform(0, 1, (d, Ntot))
+    y = np.sin(3 * X).sum(0) + 0.05 * rng.standard_normal(Ntot)
+    mean = 0.3 + 0.1 * X[0]
+    Xs = rng.uniform(0, 1, (d, M))
+    ms = 0.3 + 0.1 * Xs[0]
+    lam, amp, sig = np.array([0.4, 0.5, 0.6]), 1.3, 0.05
+    g = api.GP(X[:, :N0], y[:N0], "matern52")
+    g.update(lam, amp, sig, mean[:N0])
+    n_at = N0
+    for n in steps:
+        lp = g.append(X[:, n_at:n_at + n], y[n_at:n_at + n], mean[n_at:n_at + n])
+        n_at += n
+        post = O.gp_fit(X[:, :n_at], y[:n_at], "matern52", lam, amp, sig, mean=mean[:n_at])
+        assert abs(lp - post.logpdf) <= 1e-10 * (1 + abs(post.logpdf)), (n_at, lp, post.logpdf)
+        mu, var = g.predict(Xs, ms)
+        mu_o, var_o = O.gp_mean_and_var(post, Xs, ms)
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), n_at
+    L, z = g.factor()
+    assert L.shape == (Ntot, Ntot)
+    import scipy.linalg as sla
+    z_o = sla.solve_triangular(post.L, post.delta, lower=True)
+    assert np.allclose(L, post.L, rtol=0, atol=1e-10) and np.allclose(z, z_o, rtol=0, atol=1e-9)
+    # a later full update on the grown handle is still right
+    lp2 = g.update(lam * 1.1, amp, sig, mean)
+    post2 = O.gp_fit(X, y, "matern52", lam * 1.1, amp, sig, mean=mean)
+    assert abs(lp2 - post2.logpdf) <= 1e-10 * (1 + abs(post2.logpdf))
+    g.close()
+
+
+def test_append_zero_mean_discrete_and_errors(api, O):
+    rng = np.random.default_rng(3)
+    d, N0, n = 2, 140, 5
+    X = np.round(rng.uniform(0, 6, (d, N0 + n)) * 2) / 2 + np.array([[0.0], [0.013]])
+    y = np.cos(X).sum(0)
+    disc = [True, False]
+    g = api.GP(X[:, :N0], y[:N0], "matern32", disc)
+    with pytest.raises(api.BossError):
+        g.append(X[:, N0:], y[N0:])                      # not fitted yet
+    g.update([1.5, 2.0], 1.0, 0.1)
+    lp = g.append(X[:, N0], y[N0])                        # a single vector
+    lp = g.append(X[:, N0 + 1:], y[N0 + 1:])
+    post = O.gp_fit(X, y, "matern32", [1.5, 2.0], 1.0, 0.1, discrete=disc)
+    assert abs(lp - post.logpdf) <= 1e-10 * (1 + abs(post.logpdf))
+    Xs = rng.uniform(0, 6, (d, 17))
+    mu, var = g.predict(Xs)
+    mu_o, var_o = O.gp_mean_and_var(post, Xs)
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        g.append(np.zeros((3, 1)), [0.0])
+    # a duplicated point with (almost) no noise makes the augmented matrix singular -> PosDefException
+    X2 = rng.uniform(0, 6, (d, N0))
+    g2 = api.GP(X2, np.cos(X2).sum(0), "matern32")
+    g2.update([1.0, 1.0], 1.0, 0.0)
+    with pytest.raises(api.PosDefException):
+        for _ in range(3):
+            g2.append(X2[:, 0], np.cos(X2[:, 0]).sum())
+    assert g2.N > N0
+    g.close()
+    g2.close()
+
+
+def test_sequential_batch_am_matches_refit_loop(api, O):
+    """HipSequentialBatchAM (resident posteriors + block Cholesky appends) selects the same batch as
+    the reference's loop (batch.jl:26-38), which rebuilds the posterior from scratch each time —
+    restated here with the oracle."""
+    import boss_jl_amd as B
+    rng = np.random.default_rng(17)
+    d, N, M, P, nb = 2, 126, 300, 2, 5                 # the appends cross a 128-row block boundary
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), X[0] - X[1]])
+    Xs = np.asfortranarray(rng.uniform(0, 1, (d, M)))
+    y_max = np.array([np.inf, 0.3])
+    coefs = [1.0, 0.0]
+    prm = B.HipGPParams(np.array([[0.3, 0.5], [0.4, 0.6]]), [1.0, 0.8], [0.05, 0.02])
+    model = B.HipGaussianProcess([None] * P, [None] * P, [None] * P, mean=lambda x: [0.1, -0.2])
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness(coefs)), model,
+                         B.ExperimentData(X, Y), y_max, prm)
+    Xb, val = B.HipSequentialBatchAM(B.HipBatchAM(points=Xs), nb).maximize_acquisition(prob)
+    assert val is None and Xb.shape == (d, nb)
+    assert prob.data.X.shape == (d, N)                  # the caller's problem is untouched (deepcopy semantics)
+    Xo, Yo = X.copy(), Y.copy()
+    means = [0.1, -0.2]
+    for it in range(nb):
+        posts = [O.gp_fit(Xo, Yo[i], "matern52", prm.lengthscales[:, i], prm.amplitudes[i], prm.noise_std[i],
+                          mean=np.full(Xo.shape[1], means[i])) for i in range(P)]
+        ms = [np.full(M, means[i]) for i in range(P)]
+        acq = O.ei_acquisition(posts, Xs, coefs, y_max, O.best_so_far(coefs, Yo, y_max), means_s=ms)
+        j = int(np.argmax(acq))
+        assert np.array_equal(Xb[:, it], Xs[:, j]), it
+        yhat = np.array([O.gp_mean_and_var(posts[i], Xs[:, j:j + 1], ms[i][j:j + 1])[0][0] for i in range(P)])
+        Xo = np.hstack([Xo, Xs[:, j:j + 1]])
+        Yo = np.hstack([Yo, yhat[:, None]])
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
