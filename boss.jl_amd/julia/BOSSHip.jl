@@ -1,7 +1,3 @@
-# BOSSHip.jl — Julia glue binding libbosship.so behind BOSS.jl's plugin API (SurrogateModel /
-# ModelFitter / AcquisitionMaximizer).  Source only: no Julia toolchain exists in this pipeline; the
-# ctypes twin in ../api.py + ../model.py / fitter.py / maximizer.py is what the tests execute.
-# See INTEGRATION.md.
 module BOSSHip
 using BOSS, LinearAlgebra
 import BOSS: model_posterior_slice, data_loglike, params_loglike, _params_sampler, vectorizer, bijector,
@@ -140,5 +136,29 @@ function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options
         isnothing(b) ? 0 : 1, something(b, 0.0), ei.cons_safe ? mask : C_NULL, C_NULL, am_idx, mx)
     ccall((:boss_cand_free, lib), Cvoid, (Ptr{Cvoid},), cand[]); check(rc)
     return xs[:, am_idx[] + 1], mx[]
+end
+# ---------------------------------------------------------------- SequentialBatchAM on resident posteriors
+# batch.jl:26-38 rebuilds the posterior (an O(N^3) Cholesky) for every speculative point; here the
+# handles stay resident and each speculative observation is a block Cholesky append (O(N^2)).
+function append!(post::HipPosteriorSlice, x::AbstractVector{<:Real}, y::Real)
+    lp = Ref{Cdouble}(); X = reshape(Vector{Float64}(x), :, 1)
+    check(ccall((:boss_gp_append, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
+          post.h, 1, X, Float64[y], mean_vals(post.mean, X), lp))
+    return lp[]
+end
+Base.@kwdef struct HipSequentialBatchAM <: BOSS.AcquisitionMaximizer
+    am::HipBatchAM
+    batch_size::Int
+end
+function maximize_acquisition(sb::HipSequentialBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions)
+    problem_ = deepcopy(problem); post = BOSS.model_posterior(problem_)
+    X = reduce(hcat, map(1:sb.batch_size) do _
+        x, _ = maximize_acquisition(sb.am, problem_, options; posts = post)   # HipBatchAM with given handles
+        y = BOSS.mean(post, x)
+        BOSS.augment_dataset!(problem_, x, y)
+        foreach(i -> append!(post.slices[i], x, y[i]), eachindex(y))
+        x
+    end)
+    return X, nothing
 end
 end # module
