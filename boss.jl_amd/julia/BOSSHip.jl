@@ -116,10 +116,11 @@ Base.@kwdef struct HipBatchAM <: BOSS.AcquisitionMaximizer
     samples::Int
     max_attempts::Int = 200
 end
-function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions)
+function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions;
+                              posts = BOSS.model_posterior(problem))
     ei = problem.acquisition::BOSS.ExpectedImprovement{<:BOSS.LinFitness}
     xs = BOSS._reduce_samples([BOSS._rand_in_domain(am.x_prior, problem.domain; am.max_attempts) for _ in 1:am.samples])
-    posts = BOSS.model_posterior(problem); posts isa AbstractVector || (posts = [posts])
+    posts isa AbstractVector || (posts = [posts])
     P = BOSS.y_dim(problem); S = length(posts); M = size(xs, 2)
     hs = Ptr{Cvoid}[posts[s].slices[p].h for p in 1:P, s in 1:S]
     cand = Ref{Ptr{Cvoid}}()
