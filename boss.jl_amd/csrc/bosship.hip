@@ -19,7 +19,10 @@
 
 using namespace boss;
 
-typedef GemmDirect<4, 1, 2, 2, 16> PredG32;   // 128 rows × 32 candidates per workgroup
+#ifndef BOSS_PRED_D
+#define BOSS_PRED_D 10
+#endif
+typedef GemmDirect<4, 1, 4, 2, BOSS_PRED_D> PredG32;   // 256-row steps × 32 candidates, ring depth BOSS_PRED_D
 typedef GemmDirect<4, 1, 2, 4, 4> PredG64;   // 128 rows × 64 candidates per workgroup
 
 // ------------------------------------------------------------------------------------------
@@ -148,7 +151,7 @@ struct boss_gp {
     Ctx* ctx = nullptr;
     int kernel = 0, d = 0, N = 0, Np = 0, nblk = 0, ld = 0;
     double *Xraw = nullptr, *Xsc = nullptr, *y = nullptr, *mean = nullptr, *A = nullptr;
-    double *inv16 = nullptr, *Dinv = nullptr, *hyp = nullptr, *invlam = nullptr, *scal = nullptr;
+    double *inv16 = nullptr, *Dinv = nullptr, *Dinv2 = nullptr, *hyp = nullptr, *invlam = nullptr, *scal = nullptr;
     int* info = nullptr;
     unsigned char* discrete_dev = nullptr;     // d flags (device) or null
     std::vector<unsigned char> discrete;
@@ -286,7 +289,7 @@ static void gram_enqueue(Ctx* c, const double* Xsc, size_t xs_bstride, int d, in
 static void gp_release(boss_gp* g) {
     if (!g) return;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
-    void* ptrs[] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->hyp, g->invlam, g->scal, g->info, g->discrete_dev};
+    void* ptrs[] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->Dinv2, g->hyp, g->invlam, g->scal, g->info, g->discrete_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_res) (void)hipHostFree(g->host_res);
@@ -321,7 +324,7 @@ extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double
     g->kernel = kernel;
     g->d = d;
     g->N = N;
-    g->Np = round_up(N, BLK);
+    g->Np = round_up(N, PRED_RB);                 // whole 256-row prediction steps (padding = identity)
     g->nblk = g->Np / BLK;
     g->ld = g->Np + RHS_ROWS;
     const size_t Np = g->Np;
@@ -340,6 +343,7 @@ extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double
     GALLOC(g->A, sizeof(double) * (size_t)g->ld * Np);
     GALLOC(g->inv16, sizeof(double) * g->nblk * 8 * 256);
     GALLOC(g->Dinv, sizeof(double) * g->nblk * BLK * BLK);
+    GALLOC(g->Dinv2, sizeof(double) * (g->Np / PRED_RB) * PRED_RB * PRED_RB);
     GALLOC(g->hyp, sizeof(double) * 2);
     GALLOC(g->invlam, sizeof(double) * d);
     GALLOC(g->scal, sizeof(double) * 2);
@@ -495,16 +499,17 @@ extern "C" int boss_gp_sync(boss_gp_t* g, double* logpdf_out) {
 // any other — the right-looking factorisation restricted to one block row, O(N²) per 128 rows.
 // ------------------------------------------------------------------------------------------
 static int gp_grow(boss_gp* g, int Nnew) {
-    const int Np2 = round_up(Nnew, BLK);
+    const int Np2 = round_up(Nnew, PRED_RB);
     if (Np2 <= g->Np) return BOSS_OK;
     Ctx* c = g->ctx;
     hipStream_t s = c->stream;
     const int Np = g->Np, d = g->d, nblk2 = Np2 / BLK, ld2 = Np2 + RHS_ROWS;
     const size_t szA = sizeof(double) * (size_t)ld2 * Np2;
-    double* nw[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const size_t bytes[7] = {sizeof(double) * d * Np2, sizeof(double) * d * Np2, sizeof(double) * Np2, sizeof(double) * Np2,
-                             szA, sizeof(double) * nblk2 * 8 * 256, sizeof(double) * nblk2 * BLK * BLK};
-    for (int i = 0; i < 7; ++i)
+    double* nw[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[8] = {sizeof(double) * d * Np2, sizeof(double) * d * Np2, sizeof(double) * Np2, sizeof(double) * Np2,
+                             szA, sizeof(double) * nblk2 * 8 * 256, sizeof(double) * nblk2 * BLK * BLK,
+                             sizeof(double) * (size_t)Np2 * PRED_RB};
+    for (int i = 0; i < 8; ++i)
         if (hipMalloc((void**)&nw[i], bytes[i]) != hipSuccess) {
             for (int j = 0; j < i; ++j) (void)hipFree(nw[j]);
             return fail(BOSS_E_ALLOC, "device allocation failed while growing the posterior handle");
@@ -523,9 +528,9 @@ static int gp_grow(boss_gp* g, int Nnew) {
                             sizeof(double) * RHS_ROWS, Np, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(nw[5], g->inv16, sizeof(double) * g->nblk * 8 * 256, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
-    double* old[7] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv};
+    double* old[8] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->Dinv2};
     for (double* p : old) (void)hipFree(p);
-    g->Xraw = nw[0]; g->Xsc = nw[1]; g->y = nw[2]; g->mean = nw[3]; g->A = nw[4]; g->inv16 = nw[5]; g->Dinv = nw[6];
+    g->Xraw = nw[0]; g->Xsc = nw[1]; g->y = nw[2]; g->mean = nw[3]; g->A = nw[4]; g->inv16 = nw[5]; g->Dinv = nw[6]; g->Dinv2 = nw[7];
     g->Np = Np2;
     g->nblk = nblk2;
     g->ld = ld2;
@@ -822,6 +827,15 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         ProfScope ps(c, "dinv");
         hipLaunchKernelGGL(potrf_dinv_kernel, dim3(8, g->nblk, 1), dim3(64), 0, s, g->A, g->ld, (size_t)0, g->inv16,
                            (size_t)0, g->Dinv, (size_t)0);
+        // 256×256 inverses for the 256-row prediction steps:  lower-left quadrant = −C⁻¹ (B A⁻¹)
+        const int npair = g->Np / PRED_RB;
+        const size_t s2 = (size_t)PRED_RB * PRED_RB, s1 = (size_t)2 * BLK * BLK;
+        double* T1 = g->Dinv2 + (size_t)BLK * PRED_RB;                     // upper-right quadrant as scratch
+        hipLaunchKernelGGL(small_gemm128_kernel, dim3(16, npair), dim3(256), 0, s, g->A + BLK, g->ld,
+                           (size_t)PRED_RB * ((size_t)g->ld + 1), g->Dinv, BLK, s1, T1, PRED_RB, s2, 1.0);
+        hipLaunchKernelGGL(small_gemm128_kernel, dim3(16, npair), dim3(256), 0, s, g->Dinv + (size_t)BLK * BLK, BLK, s1,
+                           (const double*)T1, PRED_RB, s2, g->Dinv2 + BLK, PRED_RB, s2, -1.0);
+        hipLaunchKernelGGL(dinv_pair_assemble_kernel, dim3(PRED_RB, npair), dim3(256), 0, s, (const double*)g->Dinv, g->Dinv2);
         g->have_dinv = true;
     }
     const int Mp = cd->Mp;
@@ -846,7 +860,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         if (BN == 32) {
             typedef PredG32 G;
             hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
-                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz, dbg);
+                               g->N, g->Dinv2, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz, dbg);
         } else {
             typedef PredG64 G;
             hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,

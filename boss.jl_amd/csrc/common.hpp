@@ -9,6 +9,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int BLK = 128;          // block size of the blocked Cholesky / triangular solves
+constexpr int PRED_RB = 256;      // rows per prediction (forward-substitution) step; handles pad N to a multiple of it
 constexpr int RHS_ROWS = 128;     // extra row block carrying (y-m)^T through the factorisation
 constexpr int KERN_MATERN32 = 0, KERN_MATERN52 = 1, KERN_SQEXP = 2;
 constexpr double MIN_PARAM_VALUE = 1e-8;   // src/models/gaussian_process.jl:5

@@ -199,11 +199,22 @@ struct GemmNT {
 //     ring register before its load has landed (tests/test_abi_and_host.py checks the metadata).
 #ifdef BOSS_RING_PLAIN   // debugging aid: compiler-managed loads and waits
 __device__ __forceinline__ void gld16(v2d& dst, const double* p) { dst = *reinterpret_cast<const v2d*>(p); }
+template <int IMM>
+__device__ __forceinline__ void gld16s(v2d& dst, const double* base, unsigned voff) {
+    dst = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(base) + voff + IMM);
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {}
 #else
 __device__ __forceinline__ void gld16(v2d& dst, const double* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// SGPR base + 32-bit per-lane byte offset + immediate: the wave-uniform part of the address (which k
+// slice) lives on the scalar unit, the per-lane part is loop-invariant — no VALU address arithmetic
+// between the MFMAs.
+template <int IMM>
+__device__ __forceinline__ void gld16s(v2d& dst, const double* base, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -233,45 +244,66 @@ struct GemmDirect {
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: uniform control flow around the ring
         const int wr = wave / WC, wc = wave % WC;
-        const int aoff = wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda;   // per-lane element offsets
-        const int boff = wc * (TN * 16) + 2 * (lane & 15) + (lane >> 4) * ldb;
+        // per-lane BYTE offsets (loop-invariant, < 2^31: (lane>>4)·ld·8 ≤ 3·ld·8)
+        const unsigned aoff = 8u * (unsigned)(wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda);
+        const unsigned boff = 8u * (unsigned)(wc * (TN * 16) + 2 * (lane & 15) + (lane >> 4) * ldb);
         const int n = K / 4;
         if (n == 0) return;
         v2d af[D][PM], bf[D][PN];
         static_assert((PM + PN) * (D - 1) <= 63, "vmcnt is a 6-bit counter");
+        static_assert(PM <= 4 && PN <= 4, "immediate offsets are written out for up to 4 pairs");
+#define BOSS_LOAD_A(slot, Ak)                                      \
+    do {                                                           \
+        gld16s<0>(af[slot][0], Ak, aoff);                          \
+        if (PM > 1) gld16s<256>(af[slot][PM > 1 ? 1 : 0], Ak, aoff); \
+        if (PM > 2) gld16s<512>(af[slot][PM > 2 ? 2 : 0], Ak, aoff); \
+        if (PM > 3) gld16s<768>(af[slot][PM > 3 ? 3 : 0], Ak, aoff); \
+    } while (0)
+#define BOSS_LOAD_B(slot, Bk)                                      \
+    do {                                                           \
+        gld16s<0>(bf[slot][0], Bk, boff);                          \
+        if (PN > 1) gld16s<256>(bf[slot][PN > 1 ? 1 : 0], Bk, boff); \
+        if (PN > 2) gld16s<512>(bf[slot][PN > 2 ? 2 : 0], Bk, boff); \
+        if (PN > 3) gld16s<768>(bf[slot][PN > 3 ? 3 : 0], Bk, boff); \
+    } while (0)
 #pragma unroll
         for (int s = 0; s < D; ++s) {
             const int ks = s < n ? s : n - 1;
             const double* Ak = A + (size_t)(4 * ks) * lda;
             const double* Bk = B + (size_t)(4 * ks) * ldb;
-#pragma unroll
-            for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
-#pragma unroll
-            for (int t = 0; t < PN; ++t) gld16(bf[s][t], Bk + boff + t * 32);
+            BOSS_LOAD_A(s, Ak);
+            BOSS_LOAD_B(s, Bk);
         }
         // Main loop: whole ring passes, branch-free.  Before slot s is consumed exactly
         // (PM+PN)(D-1) younger ring loads are in flight (every pass re-issues every slot, clamped).
+        // Row pair p's A fragment is re-loaded right after the MFMAs that read it, so the load issue
+        // sits in the shadow of the next pair's MFMAs; the B fragments go last (every MFMA reads them).
         const int npass = n / D;
         for (int g = 0; g < npass; ++g) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
                 wait_vmcnt<(PM + PN) * (D - 1)>();
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) {
-                        const double b = bf[s][t >> 1][t & 1];
-                        acc[m][t] = mfma_f64(SIGN < 0 ? -b : b, af[s][m >> 1][m & 1], acc[m][t]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
                 int ks = (g + 1) * D + s;
                 ks = ks < n ? ks : n - 1;
                 const double* Ak = A + (size_t)(4 * ks) * lda;
                 const double* Bk = B + (size_t)(4 * ks) * ldb;
 #pragma unroll
-                for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
+                for (int p = 0; p < PM; ++p) {
 #pragma unroll
-                for (int t = 0; t < PN; ++t) gld16(bf[s][t], Bk + boff + t * 32);
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) {
+                            const double b = bf[s][t >> 1][t & 1];
+                            acc[2 * p + mm][t] = mfma_f64(SIGN < 0 ? -b : b, af[s][p][mm], acc[2 * p + mm][t]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p == 0) gld16s<0>(af[s][0], Ak, aoff);
+                    if (p == 1) gld16s<256>(af[s][PM > 1 ? 1 : 0], Ak, aoff);
+                    if (p == 2) gld16s<512>(af[s][PM > 2 ? 2 : 0], Ak, aoff);
+                    if (p == 3) gld16s<768>(af[s][PM > 3 ? 3 : 0], Ak, aoff);
+                    if (p == PM - 1) BOSS_LOAD_B(s, Bk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         wait_vmcnt<0>();                        // ring drained: the (clamped) reloads of the last pass
@@ -298,7 +330,7 @@ struct GemmDirect {
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: uniform control flow around the ring
         const int wr = wave / WC, wc = wave % WC;
-        const int aoff = wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda;
+        const unsigned aoff = 8u * (unsigned)(wr * (TM * 16) + 2 * (lane & 15) + (lane >> 4) * lda);
         const double* Bs = Bl + wc * (TN * 16) + 2 * (lane & 15) + (lane >> 4) * ldbl;
         const int n = K / 4;
         if (n == 0) return;
@@ -307,8 +339,7 @@ struct GemmDirect {
         for (int s = 0; s < D; ++s) {
             const int ks = s < n ? s : n - 1;
             const double* Ak = A + (size_t)(4 * ks) * lda;
-#pragma unroll
-            for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
+            BOSS_LOAD_A(s, Ak);
         }
         const int npass = n / D;
         for (int g = 0; g < npass; ++g) {
@@ -318,16 +349,23 @@ struct GemmDirect {
 #pragma unroll
                 for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs + (4 * (g * D + s)) * ldbl + t * 32);
                 wait_vmcnt<PM * (D - 1)>();
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[m][t] = mfma_f64(bf[t >> 1][t & 1], af[s][m >> 1][m & 1], acc[m][t]);
-                __builtin_amdgcn_sched_barrier(0);
                 int ks = (g + 1) * D + s;
                 ks = ks < n ? ks : n - 1;
                 const double* Ak = A + (size_t)(4 * ks) * lda;
 #pragma unroll
-                for (int m = 0; m < PM; ++m) gld16(af[s][m], Ak + aoff + m * 32);
+                for (int p = 0; p < PM; ++p) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int t = 0; t < TN; ++t)
+                            acc[2 * p + mm][t] = mfma_f64(bf[t >> 1][t & 1], af[s][p][mm], acc[2 * p + mm][t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p == 0) gld16s<0>(af[s][0], Ak, aoff);
+                    if (p == 1) gld16s<256>(af[s][PM > 1 ? 1 : 0], Ak, aoff);
+                    if (p == 2) gld16s<512>(af[s][PM > 2 ? 2 : 0], Ak, aoff);
+                    if (p == 3) gld16s<768>(af[s][PM > 3 ? 3 : 0], Ak, aoff);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         wait_vmcnt<0>();

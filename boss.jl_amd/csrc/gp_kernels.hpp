@@ -93,10 +93,11 @@ template <class G>
 struct PredictLds {
     static constexpr int LDR = G::BN + 16;
     static constexpr int PART = 2 * G::TN * 4;       // per-thread Σv², v·z partials, parked in LDS between row blocks
-    static constexpr int BYTES = (BLK * LDR + 2 * G::WR * G::BN + G::NTHREADS * PART) * 8;
+    static constexpr int BYTES = (G::BM * LDR + 2 * G::WR * G::BN + G::NTHREADS * PART) * 8;
 };
 
-// G = GemmDirect<WR,1,TM,TN,D> with WR·TM·16 = 128: WR waves stacked along the 128 rows, BN = 16·TN candidates.
+// G = GemmDirect<WR,1,TM,TN,D> with RB = WR·TM·16 ∈ {128, 256}: WR waves stacked along the RB rows of a
+// substitution step, BN = 16·TN candidates; Dinv holds the dense inverses of the RB×RB diagonal blocks.
 // Both GEMMs stream their A operand (L row block / Dinv_i) straight from L2 through a register
 // ring; GEMM1's B operand is the workgroup's own V slab (global, candidate-contiguous), GEMM2's
 // B operand is the R tile in LDS.  Three barriers per row block, none inside the GEMMs.
@@ -107,17 +108,18 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
                                                       const double* __restrict__ Csc, int d, int Mp, int kern,
                                                       double amp2, double* __restrict__ Vscratch,
                                                       double* __restrict__ ss_out, double* __restrict__ mz_out, int dbg) {
-    static_assert(G::BM == BLK && G::WC == 1, "row block must be 128 with waves stacked along rows");
+    static_assert(G::WC == 1 && (G::BM == BLK || G::BM == 2 * BLK), "waves stacked along a 128- or 256-row block");
+    constexpr int RB = G::BM;                          // rows per substitution step; Dinv holds RB×RB inverses
     extern __shared__ double lds[];
     constexpr int BN = G::BN, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
     double* Rs = lds;
-    double* red = Rs + BLK * LDR;
+    double* red = Rs + RB * LDR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar wave index (see gemm_f64.hpp)
     const int wr = wave, wc = 0;
     const int c0 = blockIdx.x * BN;
     double* V = Vscratch + (size_t)blockIdx.x * Np * BN;
-    const int nblk = Np / BLK;
+    const int nblk = Np / RB;
 
     // per-thread partial sums live in LDS between row blocks (slot-major [slot][tid]: conflict-free).
     // In registers they push the 64-candidate instantiation over 256 VGPRs; hipcc then spills to AGPRs
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
         for (int m = 0; m < TM; ++m)
 #pragma unroll
             for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-        if (!(dbg & 4)) G::template run<1>(A + (size_t)ib * BLK, ld, V, BN, ib * BLK, acc);
+        if (!(dbg & 4)) G::template run<1>(A + (size_t)ib * RB, ld, V, BN, ib * RB, acc);
 
         // K*_ib tile in the accumulator layout
         double r2[TM][TN][4];
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
         for (int kd = 0; kd < ((dbg & 1) ? 0 : d); ++kd) {
             double xr[TM], xc[TN][4];
 #pragma unroll
-            for (int m = 0; m < TM; ++m) xr[m] = Xsc[(size_t)kd * Np + ib * BLK + G::row_of(wr, m, lane)];
+            for (int m = 0; m < TM; ++m) xr[m] = Xsc[(size_t)kd * Np + ib * RB + G::row_of(wr, m, lane)];
 #pragma unroll
             for (int n = 0; n < TN; ++n)
 #pragma unroll
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
             const int row = G::row_of(wr, m, lane);
-            const bool live = (ib * BLK + row) < N;
+            const bool live = (ib * RB + row) < N;
 #pragma unroll
             for (int n = 0; n < TN; ++n)
 #pragma unroll
@@ -179,11 +181,11 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
 #pragma unroll
             for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
         // Dinv_i is lower triangular: rows of wave w only need k < 32 (w + 1)
-        if (!(dbg & 2)) G::run_Blds(Dinv + (size_t)ib * BLK * BLK, BLK, Rs, LDR, (TM * 16) * (wr + 1), acc2);   // K multiple of 16
+        if (!(dbg & 2)) G::run_Blds(Dinv + (size_t)ib * RB * RB, RB, Rs, LDR, (TM * 16) * (wr + 1), acc2);   // K multiple of 16
 
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
-            const int row = ib * BLK + G::row_of(wr, m, lane);
+            const int row = ib * RB + G::row_of(wr, m, lane);
             const double zr = A[(size_t)row * ld + Np];
 #pragma unroll
             for (int n = 0; n < TN; ++n)
@@ -225,6 +227,57 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
         }
         ss_out[c0 + tid] = s;
         mz_out[c0 + tid] = z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 256×256 diagonal-block inverses from the 128×128 ones (prediction with 256-row steps halves the
+// V-slab re-reads and the number of dependent steps per candidate tile):
+//     inv [ A 0 ; B C ] = [ A⁻¹ 0 ; −C⁻¹ B A⁻¹  C⁻¹ ]
+// small_gemm128_kernel: C_s = alpha · A_s · B_s for 128×128 column-major operands (32×32 output
+// tile per workgroup, grid (16, pairs)); dinv_pair_assemble_kernel copies the diagonal quadrants.
+// Runs once per factorisation, off the prediction kernel's path (≈10 µs).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_gemm128_kernel(const double* __restrict__ Abase, int lda, size_t sA,
+                                                            const double* __restrict__ Bbase, int ldb, size_t sB,
+                                                            double* __restrict__ Cbase, int ldc, size_t sC, double alpha) {
+    __shared__ double As[32][33], Bs[32][33];
+    const double* A = Abase + (size_t)blockIdx.y * sA;
+    const double* B = Bbase + (size_t)blockIdx.y * sB;
+    double* C = Cbase + (size_t)blockIdx.y * sC;
+    const int r0 = (blockIdx.x & 3) * 32, c0 = (blockIdx.x >> 2) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // ty 0..7 → 4 columns each
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < BLK; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[ty * 4 + j][tx] = A[(size_t)(k0 + ty * 4 + j) * lda + r0 + tx];      // As[k][r]
+            Bs[ty * 4 + j][tx] = B[(size_t)(c0 + ty * 4 + j) * ldb + k0 + tx];      // Bs[c][k]
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const double a = As[kk][tx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fma(a, Bs[ty * 4 + j][kk], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) C[(size_t)(c0 + ty * 4 + j) * ldc + r0 + tx] = alpha * acc[j];
+}
+
+// Dinv2_p (256×256, column-major): diagonal quadrants = Dinv128 of blocks 2p, 2p+1; upper right = 0.
+__global__ __launch_bounds__(256) void dinv_pair_assemble_kernel(const double* __restrict__ Dinv128,
+                                                                 double* __restrict__ Dinv2) {
+    const int p = blockIdx.y, c = blockIdx.x;                     // column c of the 256×256 block
+    const double* src = Dinv128 + (size_t)(2 * p + (c >> 7)) * BLK * BLK + (size_t)(c & 127) * BLK;
+    double* dst = Dinv2 + (size_t)p * 4 * BLK * BLK + (size_t)c * 2 * BLK;
+    const int r = threadIdx.x;                                    // 0..255
+    if (c < BLK) {
+        if (r < BLK) dst[r] = src[r];                             // lower-left quadrant is written by the GEMM
+    } else {
+        dst[r] = (r < BLK) ? 0.0 : src[r - BLK];
     }
 }
 

@@ -1,0 +1,14 @@
+import sys,os,time
+sys.path.insert(0,'/root/repo')
+import numpy as np
+from boss_jl_amd import api
+if os.environ.get('BOSS_LIB'): api.load_library(os.environ['BOSS_LIB'])
+sys.path.insert(0,'/root/repo/tests')
+from gpu_quick import problem
+X,y,Xs=problem(8,4096,8192)
+g=api.GP(X,y,"matern52"); g.update(np.full(8,.5),1.0,0.05)
+cand=api.Candidates(Xs); b=float(y.max())
+api.acq_ei([[g]],cand,[1.0],None,b,want_acq=False)
+api.prof_enable(0,True); api.prof_reset(0)
+for _ in range(3): api.acq_ei([[g]],cand,[1.0],None,b,want_acq=False)
+ms,n=api.prof_get(0,"predict"); print("lib=%s BOSS_DBG=%s predict %.3f ms"%(os.path.basename(os.environ.get("BOSS_LIB","new")),os.environ.get("BOSS_DBG","0"),ms/n),flush=True)
