@@ -160,6 +160,8 @@ struct boss_gp {
     double* host_res = nullptr;                // pinned: scal[2], info
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
+    hipEvent_t dinv_ev = nullptr;              // the side stream finished building Dinv / Dinv2
+    bool dinv_pending = false;
 };
 
 struct boss_cand {
@@ -295,6 +297,7 @@ static void gp_release(boss_gp* g) {
     if (g->host_res) (void)hipHostFree(g->host_res);
     if (g->host_par) (void)hipHostFree(g->host_par);
     if (g->par_ev) (void)hipEventDestroy(g->par_ev);
+    if (g->dinv_ev) (void)hipEventDestroy(g->dinv_ev);
     delete g;
 }
 
@@ -350,7 +353,8 @@ extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double
     GALLOC(g->info, sizeof(int));
     if (hipHostMalloc((void**)&g->host_res, 64, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&g->host_par, sizeof(double) * (d + 2), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&g->par_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&g->par_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->dinv_ev, hipEventDisableTiming) != hipSuccess) {
         gp_release(g);
         return fail(BOSS_E_ALLOC, "pinned allocation failed");
     }
@@ -417,11 +421,48 @@ static int gp_finish(boss_gp* g, double* logpdf_out) {
     return BOSS_OK;
 }
 
+// Dense inverses of the diagonal blocks (prediction operands): 128×128 (Dinv) and 256×256 (Dinv2,
+// lower-left quadrant = −C⁻¹ (B A⁻¹)).  Built right after a factorisation on the side stream, so it
+// overlaps the log-det reduction, the result copies and the host's return to the caller; the first
+// prediction waits on dinv_ev.  (While profiling it runs lazily on the main stream instead.)
+static void dinv_launch(boss_gp* g, hipStream_t s) {
+    hipLaunchKernelGGL(potrf_dinv_kernel, dim3(8, g->nblk, 1), dim3(64), 0, s, g->A, g->ld, (size_t)0, g->inv16, (size_t)0,
+                       g->Dinv, (size_t)0);
+    const int npair = g->Np / PRED_RB;
+    const size_t s2 = (size_t)PRED_RB * PRED_RB, s1 = (size_t)2 * BLK * BLK;
+    double* T1 = g->Dinv2 + (size_t)BLK * PRED_RB;                         // upper-right quadrant as scratch
+    hipLaunchKernelGGL(small_gemm128_kernel, dim3(16, npair), dim3(256), 0, s, g->A + BLK, g->ld,
+                       (size_t)PRED_RB * ((size_t)g->ld + 1), g->Dinv, BLK, s1, T1, PRED_RB, s2, 1.0);
+    hipLaunchKernelGGL(small_gemm128_kernel, dim3(16, npair), dim3(256), 0, s, g->Dinv + (size_t)BLK * BLK, BLK, s1,
+                       (const double*)T1, PRED_RB, s2, g->Dinv2 + BLK, PRED_RB, s2, -1.0);
+    hipLaunchKernelGGL(dinv_pair_assemble_kernel, dim3(PRED_RB, npair), dim3(256), 0, s, (const double*)g->Dinv, g->Dinv2);
+}
+
+static void dinv_eager(boss_gp* g) {
+    Ctx* c = g->ctx;
+    if (c->prof_on) return;                                  // lazily, inside its own profiling scope
+    (void)hipEventRecord(c->ev_fork, c->stream);
+    (void)hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);
+    dinv_launch(g, c->side_stream);
+    (void)hipEventRecord(g->dinv_ev, c->side_stream);
+    g->dinv_pending = true;
+    g->have_dinv = true;
+}
+
+// the side stream may still be reading A / inv16 for the previous factorisation's inverses
+static void dinv_join(boss_gp* g) {
+    if (g->dinv_pending) {
+        (void)hipStreamWaitEvent(g->ctx->stream, g->dinv_ev, 0);
+        g->dinv_pending = false;
+    }
+}
+
 // Gram + blocked Cholesky + solves + logdet of the handle's resident data under its resident
 // hyper-parameters; results land in host_res when the stream drains.
 static int factor_enqueue(boss_gp* g) {
     Ctx* c = g->ctx;
     hipStream_t s = c->stream;
+    dinv_join(g);
     HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
     {
         ProfScope ps(c, "prep");
@@ -432,6 +473,7 @@ static int factor_enqueue(boss_gp* g) {
     }
     gram_enqueue(c, g->Xsc, 0, g->d, g->N, g->Np, g->kernel, g->hyp, g->A, g->ld, 0, 1);
     potrf_enqueue(c, g->A, g->ld, g->Np, 1, 0, g->inv16, 0, g->info);
+    dinv_eager(g);
     {
         ProfScope ps(c, "logdet");
         hipLaunchKernelGGL(potrf_logdet_kernel, dim3(1, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0, g->N, g->Np,
@@ -449,6 +491,7 @@ extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double am
     if (rc) return rc;
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);                 // streams, events and scratch of the device context are shared
     hipStream_t s = c->stream;
     g->fitted = false;
     g->have_dinv = false;
@@ -527,6 +570,7 @@ static int gp_grow(boss_gp* g, int Nnew) {
     HIPCHK(hipMemcpy2DAsync(nw[4] + Np2, sizeof(double) * ld2, g->A + Np, sizeof(double) * g->ld,
                             sizeof(double) * RHS_ROWS, Np, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(nw[5], g->inv16, sizeof(double) * g->nblk * 8 * 256, hipMemcpyDeviceToDevice, s));
+    dinv_join(g);
     HIPCHK(hipStreamSynchronize(s));
     double* old[8] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->Dinv2};
     for (double* p : old) (void)hipFree(p);
@@ -543,6 +587,7 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
     if (!g || n < 1 || !X_new || !y_new) return fail(BOSS_E_INVALID, "need a handle, n >= 1 and non-NULL X_new, y_new");
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
     if (g->pending) {
         int rc0 = gp_finish(g, nullptr);
         if (rc0) return rc0;
@@ -574,6 +619,7 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
         if (rc) return rc;
     } else {
         const int Np = g->Np, ld = g->ld;
+        dinv_join(g);
         HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
         hipLaunchKernelGGL(scale_points_kernel, dim3((Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc, (size_t)0,
                            g->invlam, d, Np);
@@ -592,6 +638,7 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
             hipLaunchKernelGGL(potrf_trsm_kernel, dim3(1, 1, 1), dim3(64), 0, s, g->A, ld, (size_t)0, kb, g->inv16, (size_t)0,
                                Np);
         }
+        dinv_eager(g);
         hipLaunchKernelGGL(potrf_logdet_kernel, dim3(1, 1, 1), dim3(256), 0, s, g->A, ld, (size_t)0, N1, Np, g->scal);
         HIPCHK(hipMemcpyAsync(g->host_res, g->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(&g->host_res[2], g->info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -627,6 +674,7 @@ extern "C" void boss_gp_free(boss_gp_t* g) {
     if (g->ctx) {
         (void)hipSetDevice(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->stream);
+        if (g->dinv_pending) (void)hipEventSynchronize(g->dinv_ev);
     }
     gp_release(g);
 }
@@ -665,6 +713,7 @@ extern "C" int boss_gp_loglike_batch(int device, int kernel, int d, int N, const
     Ctx* c;
     int rc = get_ctx(device, &c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mtx);
     hipStream_t s = c->stream;
     const int Np = round_up(N, BLK), nblk = Np / BLK, ld = Np + RHS_ROWS;
     const size_t bstride = (size_t)ld * Np;
@@ -823,19 +872,10 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
     if (cd->ctx != c) return fail(BOSS_E_INVALID, "candidates and posterior live on different devices");
     if (cd->d != g->d) return fail(BOSS_E_INVALID, "candidate dimension differs from the model's x_dim");
+    dinv_join(g);
     if (!g->have_dinv) {
         ProfScope ps(c, "dinv");
-        hipLaunchKernelGGL(potrf_dinv_kernel, dim3(8, g->nblk, 1), dim3(64), 0, s, g->A, g->ld, (size_t)0, g->inv16,
-                           (size_t)0, g->Dinv, (size_t)0);
-        // 256×256 inverses for the 256-row prediction steps:  lower-left quadrant = −C⁻¹ (B A⁻¹)
-        const int npair = g->Np / PRED_RB;
-        const size_t s2 = (size_t)PRED_RB * PRED_RB, s1 = (size_t)2 * BLK * BLK;
-        double* T1 = g->Dinv2 + (size_t)BLK * PRED_RB;                     // upper-right quadrant as scratch
-        hipLaunchKernelGGL(small_gemm128_kernel, dim3(16, npair), dim3(256), 0, s, g->A + BLK, g->ld,
-                           (size_t)PRED_RB * ((size_t)g->ld + 1), g->Dinv, BLK, s1, T1, PRED_RB, s2, 1.0);
-        hipLaunchKernelGGL(small_gemm128_kernel, dim3(16, npair), dim3(256), 0, s, g->Dinv + (size_t)BLK * BLK, BLK, s1,
-                           (const double*)T1, PRED_RB, s2, g->Dinv2 + BLK, PRED_RB, s2, -1.0);
-        hipLaunchKernelGGL(dinv_pair_assemble_kernel, dim3(PRED_RB, npair), dim3(256), 0, s, (const double*)g->Dinv, g->Dinv2);
+        dinv_launch(g, s);
         g->have_dinv = true;
     }
     const int Mp = cd->Mp;
@@ -847,11 +887,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     if (rc) return rc;
     rc = ws_reserve(c->vscratch, sizeof(double) * (size_t)tiles * BN * g->Np);
     if (rc) return rc;
-    rc = ws_reserve(c->pred, sizeof(double) * 2 * (size_t)Mp);
-    if (rc) return rc;
     double* Csc = (double*)c->csc.p;
-    double* ss = (double*)c->pred.p;
-    double* mz = ss + Mp;
     hipLaunchKernelGGL(scale_cand_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, cd->Craw, Csc, g->invlam,
                        g->discrete_dev, g->d, Mp);
     const int dbg = getenv("BOSS_DBG") ? atoi(getenv("BOSS_DBG")) : 0;
@@ -860,15 +896,13 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         if (BN == 32) {
             typedef PredG32 G;
             hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
-                               g->N, g->Dinv2, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz, dbg);
+                               g->N, g->Dinv2, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, mean_s_dev, cd->M, mu, var, dbg);
         } else {
             typedef PredG64 G;
             hipLaunchKernelGGL(predict_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
-                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, ss, mz, dbg);
+                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, (double*)c->vscratch.p, mean_s_dev, cd->M, mu, var, dbg);
         }
     }
-    hipLaunchKernelGGL(predict_finalize_kernel, dim3((cd->M + 255) / 256), dim3(256), 0, s, ss, mz, mean_s_dev, g->amp2,
-                       cd->M, mu, var);
     HIPCHK(hipGetLastError());
     return BOSS_OK;
 }
@@ -881,6 +915,7 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);                 // the per-device scratch areas are shared
     boss_cand_t* cd = nullptr;
     int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
     if (rc) return rc;
@@ -929,6 +964,7 @@ extern "C" int boss_gp_predict_cov(boss_gp_t* g, int M, const double* Xs, const 
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);                 // the per-device scratch areas are shared
     boss_cand_t* cd = nullptr;
     int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
     if (rc) return rc;
@@ -978,6 +1014,25 @@ extern "C" int boss_gp_predict_cov(boss_gp_t* g, int M, const double* Xs, const 
 // ------------------------------------------------------------------------------------------
 // acquisition
 // ------------------------------------------------------------------------------------------
+// EI parameters: by value in the kernel arguments for P <= EI_MAXP, else in device arrays.
+static int ei_params(Ctx* c, hipStream_t s, int P, const double* fit_coefs, const double* y_max, int has_best, double best,
+                     EiPar* par, double* dcoef, double* dymax) {
+    par->P = P;
+    par->mode = (has_best ? 1 : 0) | (y_max ? 2 : 0);
+    par->best = best;
+    if (P <= EI_MAXP) {
+        for (int p = 0; p < P; ++p) {
+            par->coefs[p] = fit_coefs[p];
+            par->ymax[p] = y_max ? y_max[p] : std::numeric_limits<double>::infinity();
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(dcoef, fit_coefs, sizeof(double) * P, hipMemcpyHostToDevice, s));
+        if (y_max) HIPCHK(hipMemcpyAsync(dymax, y_max, sizeof(double) * P, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return BOSS_OK;
+}
+
 extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_t* cand, const double* mean_Xs,
                            const double* fit_coefs, const double* y_max, int has_best, double best,
                            const unsigned char* valid_mask, double* acq_out, long* argmax_out, double* max_out) {
@@ -989,10 +1044,11 @@ extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_
         if (gps[i]->ctx != c) return fail(BOSS_E_INVALID, "all handles and candidates must live on one device");
         if (!gps[i]->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
     }
+    std::lock_guard<std::mutex> lk(c->mtx);                 // the per-device scratch areas are shared
     hipStream_t s = c->stream;
     const int M = cand->M;
-    // device scratch: mu[P][M] | var[P][M] | acq[M] | mean[P][M] | coefs[P] | ymax[P] | out val | out idx | mask
-    const size_t nd = (size_t)3 * P * M + M + 2 * P + 4;
+    // device scratch: mu[P][M] | var[P][M] | acq[M] | mean[P][M] | coefs[P] | ymax[P] | mask
+    const size_t nd = (size_t)3 * P * M + M + 2 * P;
     {
         int rc = ws_reserve(c->acq, sizeof(double) * nd + M);      // grow-only: no hipMalloc/hipFree (= device sync) per call
         if (rc) return rc;
@@ -1004,18 +1060,16 @@ extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_
     double* dmean = dacq + M;
     double* dcoef = dmean + (size_t)P * M;
     double* dymax = dcoef + P;
-    double* dval = dymax + P;
-    long* didx = (long*)(dval + 1);
     unsigned char* dmask = (unsigned char*)(dev + nd);
-    auto cleanup = [&]() { (void)hipStreamSynchronize(s); };
-    (void)hipMemcpyAsync(dcoef, fit_coefs, sizeof(double) * P, hipMemcpyHostToDevice, s);
-    if (y_max) (void)hipMemcpyAsync(dymax, y_max, sizeof(double) * P, hipMemcpyHostToDevice, s);
+    double* hres = (double*)c->pinned;                      // written by the epilogue kernel (mapped host memory)
+    EiPar par;
+    int rc = ei_params(c, s, P, fit_coefs, y_max, has_best, best, &par, dcoef, dymax);
+    if (rc) return rc;
     if (valid_mask) (void)hipMemcpyAsync(dmask, valid_mask, M, hipMemcpyHostToDevice, s);
-    (void)hipMemsetAsync(dacq, 0, sizeof(double) * M, s);
-    const int mode = (has_best ? 1 : 0) | (y_max ? 2 : 0);
+    if (S > 1) (void)hipMemsetAsync(dacq, 0, sizeof(double) * M, s);
     std::vector<double> hmean;
     for (int sm = 0; sm < S; ++sm) {
-        if (mode != 0) {
+        if (par.mode != 0) {
             if (mean_Xs) {
                 // caller layout p + P*(j + M*s)  →  device [p][j]
                 hmean.resize((size_t)P * M);
@@ -1025,36 +1079,29 @@ extern "C" int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_
                 (void)hipStreamSynchronize(s);
             }
             for (int p = 0; p < P; ++p) {
-                int rc = predict_enqueue(gps[p + (size_t)P * sm], cand, mean_Xs ? dmean + (size_t)p * M : nullptr,
-                                         dmu + (size_t)p * M, dvar + (size_t)p * M);
+                rc = predict_enqueue(gps[p + (size_t)P * sm], cand, mean_Xs ? dmean + (size_t)p * M : nullptr,
+                                     dmu + (size_t)p * M, dvar + (size_t)p * M);
                 if (rc) {
-                    cleanup();
+                    (void)hipStreamSynchronize(s);
                     return rc;
                 }
             }
-            ProfScope ps(c, "ei");
-            hipLaunchKernelGGL(ei_accumulate_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dmu, dvar, M, P, M, dcoef,
-                               y_max ? dymax : nullptr, mode, best, dacq);
         }
+        ProfScope ps(c, sm + 1 < S ? "ei" : "argmax");
+        if (sm + 1 < S)
+            hipLaunchKernelGGL(ei_accumulate_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dmu, dvar, M, M, par, dcoef, dymax,
+                               dacq);
+        else                                                 // last sample: EI + BI average + mask + arg-max in one launch
+            hipLaunchKernelGGL(acq_epilogue_kernel, dim3(1), dim3(ACQ_EPI_THREADS), 0, s, dmu, dvar, M, M, par, dcoef, dymax,
+                               dacq, S > 1 ? 1 : 0, 1.0 / S, valid_mask ? dmask : nullptr, hres);
     }
-    {
-        ProfScope ps(c, "argmax");
-        hipLaunchKernelGGL(acq_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dacq, M, 1.0 / S,
-                           valid_mask ? dmask : nullptr);
-        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, s, dacq, M, dval, didx);
-    }
-    double hval = 0.0;
-    long hidx = -1;
-    (void)hipMemcpyAsync(&hval, dval, sizeof(double), hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(&hidx, didx, sizeof(long), hipMemcpyDeviceToHost, s);
     if (acq_out) (void)hipMemcpyAsync(acq_out, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
     hipError_t e2 = hipGetLastError();
-    cleanup();
     if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e2));
-    if (argmax_out) *argmax_out = hidx;
-    if (max_out) *max_out = hval;
+    if (argmax_out) std::memcpy(argmax_out, &hres[1], sizeof(long));
+    if (max_out) *max_out = hres[0];
     return BOSS_OK;
 }
 
@@ -1069,9 +1116,10 @@ extern "C" int boss_acq_ei_moments(int device, int P, int S, int M, const double
     int rc = get_ctx(device, &c);
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
     hipStream_t s = c->stream;
     const size_t pm = (size_t)P * M;
-    const size_t nd = 2 * pm * S + M + 2 * P + 4;
+    const size_t nd = 2 * pm * S + M + 2 * P;
     rc = ws_reserve(c->acq, sizeof(double) * nd + M);
     if (rc) return rc;
     double* dev = (double*)c->acq.p;
@@ -1080,31 +1128,25 @@ extern "C" int boss_acq_ei_moments(int device, int P, int S, int M, const double
     double* dacq = dvar + pm * S;
     double* dcoef = dacq + M;
     double* dymax = dcoef + P;
-    double* dval = dymax + P;
-    long* didx = (long*)(dval + 1);
     unsigned char* dmask = (unsigned char*)(dev + nd);
+    double* hres = (double*)c->pinned;
+    EiPar par;
+    rc = ei_params(c, s, P, fit_coefs, y_max, has_best, best, &par, dcoef, dymax);
+    if (rc) return rc;
     (void)hipMemcpyAsync(dmu, mu, sizeof(double) * pm * S, hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(dvar, var, sizeof(double) * pm * S, hipMemcpyHostToDevice, s);
-    (void)hipMemcpyAsync(dcoef, fit_coefs, sizeof(double) * P, hipMemcpyHostToDevice, s);
-    if (y_max) (void)hipMemcpyAsync(dymax, y_max, sizeof(double) * P, hipMemcpyHostToDevice, s);
     if (valid_mask) (void)hipMemcpyAsync(dmask, valid_mask, M, hipMemcpyHostToDevice, s);
-    (void)hipMemsetAsync(dacq, 0, sizeof(double) * M, s);
-    const int mode = (has_best ? 1 : 0) | (y_max ? 2 : 0);
-    for (int sm = 0; sm < S; ++sm)
-        hipLaunchKernelGGL(ei_accumulate_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dmu + pm * sm, dvar + pm * sm, M,
-                           P, M, dcoef, y_max ? dymax : nullptr, mode, best, dacq);
-    hipLaunchKernelGGL(acq_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dacq, M, 1.0 / S,
-                       valid_mask ? dmask : nullptr);
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, s, dacq, M, dval, didx);
-    double hval = 0.0;
-    long hidx = -1;
-    (void)hipMemcpyAsync(&hval, dval, sizeof(double), hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(&hidx, didx, sizeof(long), hipMemcpyDeviceToHost, s);
+    if (S > 1) (void)hipMemsetAsync(dacq, 0, sizeof(double) * M, s);
+    for (int sm = 0; sm + 1 < S; ++sm)
+        hipLaunchKernelGGL(ei_accumulate_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dmu + pm * sm, dvar + pm * sm, M, M, par,
+                           dcoef, dymax, dacq);
+    hipLaunchKernelGGL(acq_epilogue_kernel, dim3(1), dim3(ACQ_EPI_THREADS), 0, s, dmu + pm * (S - 1), dvar + pm * (S - 1), M, M,
+                       par, dcoef, dymax, dacq, S > 1 ? 1 : 0, 1.0 / S, valid_mask ? dmask : nullptr, hres);
     if (acq_out) (void)hipMemcpyAsync(acq_out, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
-    if (argmax_out) *argmax_out = hidx;
-    if (max_out) *max_out = hval;
+    if (argmax_out) std::memcpy(argmax_out, &hres[1], sizeof(long));
+    if (max_out) *max_out = hres[0];
     return BOSS_OK;
 }
 

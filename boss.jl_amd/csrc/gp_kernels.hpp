@@ -107,7 +107,8 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
                                                       const double* __restrict__ Xsc,
                                                       const double* __restrict__ Csc, int d, int Mp, int kern,
                                                       double amp2, double* __restrict__ Vscratch,
-                                                      double* __restrict__ ss_out, double* __restrict__ mz_out, int dbg) {
+                                                      const double* __restrict__ mean_s, int M,
+                                                      double* __restrict__ mu_out, double* __restrict__ var_out, int dbg) {
     static_assert(G::WC == 1 && (G::BM == BLK || G::BM == 2 * BLK), "waves stacked along a 128- or 256-row block");
     constexpr int RB = G::BM;                          // rows per substitution step; Dinv holds RB×RB inverses
     extern __shared__ double lds[];
@@ -225,8 +226,12 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
             s += red[w * BN + tid];
             z += red[G::WR * BN + w * BN + tid];
         }
-        ss_out[c0 + tid] = s;
-        mz_out[c0 + tid] = z;
+        // μ = m(x*) + V^T z ;  σ² = k(x*,x*) − Σ V² + 1e-18   (unclipped; clipping is the consumer's job)
+        const int j = c0 + tid;
+        if (j < M) {
+            mu_out[j] = (mean_s ? mean_s[j] : 0.0) + z;
+            var_out[j] = amp2 - s + PREDICT_JITTER;
+        }
     }
 }
 
@@ -279,16 +284,6 @@ __global__ __launch_bounds__(256) void dinv_pair_assemble_kernel(const double* _
     } else {
         dst[r] = (r < BLK) ? 0.0 : src[r - BLK];
     }
-}
-
-// μ = m(x*) + V^T z ;  σ² = k(x*,x*) − Σ V² + 1e-18   (unclipped; clipping is the consumer's job)
-__global__ void predict_finalize_kernel(const double* __restrict__ ss, const double* __restrict__ mz,
-                                        const double* __restrict__ mean_s, double amp2, int M,
-                                        double* __restrict__ mu, double* __restrict__ var) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    mu[j] = (mean_s ? mean_s[j] : 0.0) + mz[j];
-    var[j] = amp2 - ss[j] + PREDICT_JITTER;
 }
 
 // a5: full posterior covariance  Σ = K** − VᵀV + 1e-18·I  (mean_and_cov, gaussian_process.jl:180-184;
@@ -345,37 +340,46 @@ __global__ void clip_var_kernel(double* __restrict__ var, int M, unsigned long l
 }
 
 // ------------------------------------------------------------------------------------------
-// K8 EI·feas epilogue for one hyper-parameter sample: acq_sum[j] += acq_s(x_j)
-// (expected_improvement.jl:68-101,113-114).  mu/var are P×M (row p at p*ldm).
+// K8 EI·feas epilogue (expected_improvement.jl:68-101,113-114).  mu/var are P×M (row p at p*ldm).
 // mode bit0: has best_yet, bit1: constrained.  A candidate whose variance is < -1e-8 in any
 // output is poisoned with -Inf (SafeFunction semantics, src/acquisition.jl:21-25).
+// The P fitness coefficients / constraints travel in the kernel arguments (no H2D copies) when
+// P <= EI_MAXP, otherwise in device arrays.
 // ------------------------------------------------------------------------------------------
-__global__ void ei_accumulate_kernel(const double* __restrict__ mu, const double* __restrict__ var, int ldm, int P,
-                                     int M, const double* __restrict__ coefs, const double* __restrict__ ymax,
-                                     int mode, double best, double* __restrict__ acq_sum) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    if (mode == 0) return;                                  // construct_ei(…, nothing, …, nothing): acq ≡ 0
+constexpr int EI_MAXP = 16;
+struct EiPar {
+    int P, mode;
+    double best;
+    double coefs[EI_MAXP], ymax[EI_MAXP];
+};
+
+__device__ __forceinline__ double ei_value(const double* __restrict__ mu, const double* __restrict__ var, int ldm, int j,
+                                           const EiPar& par, const double* __restrict__ coefs_dev,
+                                           const double* __restrict__ ymax_dev) {
+    const int P = par.P, mode = par.mode;
+    if (mode == 0) return 0.0;                              // construct_ei(…, nothing, …, nothing): acq ≡ 0
     double muf = 0.0, vf = 0.0, fp = 1.0;
     bool poison = false;
     for (int p = 0; p < P; ++p) {
+        const double cf = (P <= EI_MAXP) ? par.coefs[p] : coefs_dev[p];
+        const double ym = (mode & 2) ? ((P <= EI_MAXP) ? par.ymax[p] : ymax_dev[p]) : INFINITY;
         double m = mu[(size_t)p * ldm + j], v = var[(size_t)p * ldm + j];
         if (v < 0.0) {
             if (v >= -MAX_NEG_VAR) v = 0.0;
             else poison = true;
         }
-        muf = __builtin_fma(coefs[p], m, muf);
-        vf = __builtin_fma(coefs[p] * coefs[p], v, vf);
-        if ((mode & 2) && !(isinf(ymax[p]) && ymax[p] > 0.0)) {
+        muf = __builtin_fma(cf, m, muf);
+        vf = __builtin_fma(cf * cf, v, vf);
+        if ((mode & 2) && !(isinf(ym) && ym > 0.0)) {
             double s = sqrt(v);
-            double z = (s == 0.0 && ymax[p] == m) ? INFINITY : (ymax[p] - m) / s;
+            double z = (s == 0.0 && ym == m) ? INFINITY : (ym - m) / s;
             fp *= normcdf_dev(z);
         }
     }
     double acq;
     if (mode & 1) {
         double sf = sqrt(vf);
-        double diff = muf - best;
+        double diff = muf - par.best;
         double ei;
         if (diff == 0.0 && sf == 0.0) ei = 0.0;
         else {
@@ -386,18 +390,17 @@ __global__ void ei_accumulate_kernel(const double* __restrict__ mu, const double
     } else {
         acq = fp;
     }
-    if (poison) acq = -INFINITY;
-    acq_sum[j] += acq;
+    return poison ? -INFINITY : acq;
 }
 
-// acq = acq_sum / S, masked to 0 outside the domain (make_safe, expected_improvement.jl:58-65)
-__global__ void acq_finalize_kernel(double* __restrict__ acq, int M, double inv_s,
-                                    const unsigned char* __restrict__ mask) {
+// BI: acq_sum[j] += acq_s(x_j) for every hyper-parameter sample but the last (the last one is folded
+// into acq_epilogue_kernel).
+__global__ void ei_accumulate_kernel(const double* __restrict__ mu, const double* __restrict__ var, int ldm, int M,
+                                     EiPar par, const double* __restrict__ coefs_dev,
+                                     const double* __restrict__ ymax_dev, double* __restrict__ acq_sum) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
-    double a = acq[j] * inv_s;
-    if (mask && !mask[j]) a = 0.0;
-    acq[j] = a;
+    acq_sum[j] += ei_value(mu, var, ldm, j, par, coefs_dev, ymax_dev);
 }
 
 // K9 arg-max (Julia argmax: first index of the maximum, NaN counts as the largest value).
@@ -407,24 +410,40 @@ __device__ __forceinline__ bool better(double a, long ia, double b, long ib) {
     if (!an && a != b) return a > b;
     return ia < ib;
 }
-__global__ __launch_bounds__(256) void argmax_kernel(const double* __restrict__ vals, int M, double* __restrict__ out_val,
-                                                     long* __restrict__ out_idx) {
-    __shared__ double sv[256];
-    __shared__ long si[256];
+
+// Fused epilogue of one acquisition batch (one 1024-thread workgroup):
+//   acq[j] = (acq_sum[j] (previous samples, if any) + acq_S(x_j)) / S, masked to 0 outside the domain
+//   (make_safe, expected_improvement.jl:58-65), written back to acq_sum, and its first-index
+//   arg-max, written straight into host-pinned memory (res[0] = value, res[1] = index as int64).
+constexpr int ACQ_EPI_THREADS = 1024;
+__global__ __launch_bounds__(ACQ_EPI_THREADS) void acq_epilogue_kernel(const double* __restrict__ mu,
+                                                                       const double* __restrict__ var, int ldm, int M,
+                                                                       EiPar par, const double* __restrict__ coefs_dev,
+                                                                       const double* __restrict__ ymax_dev,
+                                                                       double* __restrict__ acq_sum, int have_prev,
+                                                                       double inv_s, const unsigned char* __restrict__ mask,
+                                                                       double* __restrict__ res) {
+    __shared__ double sv[ACQ_EPI_THREADS];
+    __shared__ long si[ACQ_EPI_THREADS];
+    constexpr long NONE = 0x7fffffffffffffffL;
     double bv = -INFINITY;
-    long bi = 0x7fffffffffffffffL;
-    for (int j = threadIdx.x; j < M; j += 256) {
-        double v = vals[j];
-        if (bi == 0x7fffffffffffffffL || better(v, j, bv, bi)) { bv = v; bi = j; }
+    long bi = NONE;
+    for (int j = threadIdx.x; j < M; j += ACQ_EPI_THREADS) {
+        double a = ei_value(mu, var, ldm, j, par, coefs_dev, ymax_dev);
+        if (have_prev) a += acq_sum[j];
+        a *= inv_s;
+        if (mask && !mask[j]) a = 0.0;
+        acq_sum[j] = a;
+        if (bi == NONE || better(a, j, bv, bi)) { bv = a; bi = j; }
     }
     sv[threadIdx.x] = bv;
     si[threadIdx.x] = bi;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = ACQ_EPI_THREADS / 2; st > 0; st >>= 1) {
         if (threadIdx.x < st) {
-            double ov = sv[threadIdx.x + st];
-            long oi = si[threadIdx.x + st];
-            if (oi != 0x7fffffffffffffffL && (si[threadIdx.x] == 0x7fffffffffffffffL || better(ov, oi, sv[threadIdx.x], si[threadIdx.x]))) {
+            const double ov = sv[threadIdx.x + st];
+            const long oi = si[threadIdx.x + st];
+            if (oi != NONE && (si[threadIdx.x] == NONE || better(ov, oi, sv[threadIdx.x], si[threadIdx.x]))) {
                 sv[threadIdx.x] = ov;
                 si[threadIdx.x] = oi;
             }
@@ -432,8 +451,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const double* __restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out_val[0] = sv[0];
-        out_idx[0] = si[0];
+        res[0] = sv[0];
+        reinterpret_cast<long*>(res)[1] = si[0];
     }
 }
 
