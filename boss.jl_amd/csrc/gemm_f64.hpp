@@ -383,6 +383,122 @@ struct GemmDirect {
             }
         }
     }
+
+    // Triangular-balanced variant of run_Blds for PM == 2, WC == 1 and a LOWER-TRIANGULAR A block of
+    // BM = 8·32 rows: this wave's two row pairs are the 32-row groups g0 = wave and g1 = 7 − wave, and
+    // pair p only multiplies the k < 32 (g_p + 1) columns that are non-zero in its rows.  Every wave
+    // then issues 72 four-MFMA stages (contiguous 64-row slices would give wave 3 128 of them).
+    // acc rows: tiles 0,1 ↔ group g0, tiles 2,3 ↔ group g1 (see tri_row_of).
+    __device__ static __forceinline__ int tri_group(int wave, int p) { return p == 0 ? wave : 7 - wave; }
+    __device__ static __forceinline__ int tri_row_of(int wave, int m, int lane) {
+        return 32 * tri_group(wave, m >> 1) + 2 * (lane & 15) + (m & 1);
+    }
+    __device__ static __forceinline__ void run_Blds_tri(const double* __restrict__ A, int lda,
+                                                        const double* __restrict__ Bl, int ldbl,
+                                                        v4d (&acc)[TM][TN]) {
+        static_assert(PM == 2 && WC == 1 && WR == 4 && BM == 256, "balanced pairing is written for 4 waves × 2 row pairs");
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int g0 = wave, g1 = 7 - wave;
+        const unsigned off0 = 8u * (unsigned)(32 * g0 + 2 * (lane & 15) + (lane >> 4) * lda);
+        const unsigned off1 = 8u * (unsigned)(32 * g1 + 2 * (lane & 15) + (lane >> 4) * lda);
+        const double* Bs = Bl + 2 * (lane & 15) + (lane >> 4) * ldbl;
+        const int n0 = 8 * (g0 + 1), n1 = 8 * (g1 + 1);          // k-substeps (of 4 columns) per pair
+        {   // ---- phase 1: k-substeps [0, n0), both pairs
+            v2d af[D][2];
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const int ks = s < n0 ? s : n0 - 1;
+                const double* Ak = A + (size_t)(4 * ks) * lda;
+                gld16s<0>(af[s][0], Ak, off0);
+                gld16s<0>(af[s][1], Ak, off1);
+            }
+            const int npass = n0 / D;
+            for (int g = 0; g < npass; ++g) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    v2d bf[PN];
+#pragma unroll
+                    for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs + (4 * (g * D + s)) * ldbl + t * 32);
+                    wait_vmcnt<2 * (D - 1)>();
+                    int ks = (g + 1) * D + s;
+                    ks = ks < n0 ? ks : n0 - 1;
+                    const double* Ak = A + (size_t)(4 * ks) * lda;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                            for (int t = 0; t < TN; ++t)
+                                acc[2 * p + mm][t] = mfma_f64(bf[t >> 1][t & 1], af[s][p][mm], acc[2 * p + mm][t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (p == 0) gld16s<0>(af[s][0], Ak, off0);
+                        else gld16s<0>(af[s][1], Ak, off1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            wait_vmcnt<0>();
+            const int rem = n0 - npass * D;
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                if (s < rem) {
+                    v2d bf[PN];
+#pragma unroll
+                    for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs + (4 * (npass * D + s)) * ldbl + t * 32);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) acc[m][t] = mfma_f64(bf[t >> 1][t & 1], af[s][m >> 1][m & 1], acc[m][t]);
+                }
+            }
+        }
+        {   // ---- phase 2: k-substeps [n0, n1), pair 1 only (rows of group g1 reach further right)
+            const int n2 = n1 - n0;
+            if (n2 <= 0) return;
+            const double* A2 = A + (size_t)(4 * n0) * lda;
+            const double* Bs2 = Bs + (size_t)(4 * n0) * ldbl;
+            v2d af[D];
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const int ks = s < n2 ? s : n2 - 1;
+                gld16s<0>(af[s], A2 + (size_t)(4 * ks) * lda, off1);
+            }
+            const int npass = n2 / D;
+            for (int g = 0; g < npass; ++g) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    v2d bf[PN];
+#pragma unroll
+                    for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs2 + (4 * (g * D + s)) * ldbl + t * 32);
+                    wait_vmcnt<D - 1>();
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) acc[2 + mm][t] = mfma_f64(bf[t >> 1][t & 1], af[s][mm], acc[2 + mm][t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    int ks = (g + 1) * D + s;
+                    ks = ks < n2 ? ks : n2 - 1;
+                    gld16s<0>(af[s], A2 + (size_t)(4 * ks) * lda, off1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            wait_vmcnt<0>();
+            const int rem = n2 - npass * D;
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                if (s < rem) {
+                    v2d bf[PN];
+#pragma unroll
+                    for (int t = 0; t < PN; ++t) bf[t] = *reinterpret_cast<const v2d*>(Bs2 + (4 * (npass * D + s)) * ldbl + t * 32);
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) acc[2 + mm][t] = mfma_f64(bf[t >> 1][t & 1], af[s][mm], acc[2 + mm][t]);
+                }
+            }
+        }
+    }
 };
 
 }  // namespace boss

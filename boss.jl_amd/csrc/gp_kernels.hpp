@@ -181,12 +181,20 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
         for (int m = 0; m < TM; ++m)
 #pragma unroll
             for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-        // Dinv_i is lower triangular: rows of wave w only need k < 32 (w + 1)
-        if (!(dbg & 2)) G::run_Blds(Dinv + (size_t)ib * RB * RB, RB, Rs, LDR, (TM * 16) * (wr + 1), acc2);   // K multiple of 16
+        // Dinv_i is lower triangular: a row only needs the k up to its own index.  With 256-row steps the
+        // waves take the 32-row groups {w, 7-w} (equal work); otherwise contiguous slices, k < 32 (w + 1).
+        constexpr bool TRI = (RB == 256 && G::PM == 2 && G::WR == 4);
+        if (!(dbg & 2)) {
+            if constexpr (TRI) G::run_Blds_tri(Dinv + (size_t)ib * RB * RB, RB, Rs, LDR, acc2);
+            else G::run_Blds(Dinv + (size_t)ib * RB * RB, RB, Rs, LDR, (TM * 16) * (wr + 1), acc2);   // K multiple of 16
+        }
 
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
-            const int row = ib * RB + G::row_of(wr, m, lane);
+            int rloc;
+            if constexpr (TRI) rloc = G::tri_row_of(wr, m, lane);
+            else rloc = G::row_of(wr, m, lane);
+            const int row = ib * RB + rloc;
             const double zr = A[(size_t)row * ld + Np];
 #pragma unroll
             for (int n = 0; n < TN; ++n)
