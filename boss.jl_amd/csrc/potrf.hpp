@@ -26,6 +26,10 @@ constexpr int DIAG_LDS_BYTES = (BLK * LDD + 256) * 8;  // block + E tile of the 
 // X(r,c) at c*16+r, zero above the diagonal).
 // info: first failing global column + 1 (0 = success) — PosDefException analogue.
 // ------------------------------------------------------------------------------------------
+// Workgroup barrier for data exchanged through LDS only: unlike __syncthreads() it does not wait for
+// this wave's outstanding global stores (inv16 goes to global right before barrier 1).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int DIAG_THREADS = 1024;   // 16 waves = 4 per SIMD: single-wave fp64 VALU / LDS / MFMA issue rates are 3-5x below the multi-wave rates
 
 // 16×16 tile in the "transposed C" layout: register i of lane l = element (row = l&15, col = (l>>4)+4i),
@@ -54,6 +58,8 @@ __device__ __forceinline__ void chol16_with_inverse(v4d& S, v4d& E, int lane, in
             E[t] = colj ? E[t] * inv : E[t];
             if (j < 3) {
                 const int src = 16 * j + r16;          // same row, column j of the micro-panel
+                // (v_permlane16_swap + v_permlane32_swap can do this row broadcast on the VALU, but measured
+                //  slower here than the ds_bpermute round trip: 30.8 vs 27.1 µs per block)
                 const double lS = __shfl(S[t], src), lE = __shfl(E[t], src);
                 double lc = readlane_f64(S[t], 16 * j + 4 * t + j + 1);
                 if (j < 2) {
@@ -132,18 +138,22 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
                 Es[r16 * 16 + c] = E[i];                                  // E(row r16, col c)
                 inv16[jb * 256 + r16 * 16 + c] = E[i];                    // inv(L16)(c, r16) = E(r16, c)
             }
-        } else if (jb > 0) {
-            // rest of the rank-16 update with panel jb-1 (tile (jb,jb) was done by wave 0 in phase C)
+        } else if (jb > 0 && (wave & 3) != 0) {
+            // rest of the rank-16 update with panel jb-1 (tile (jb,jb) was done by wave 0 in phase C).
+            // Waves 4, 8, 12 share wave 0's SIMD: they stay idle here, so the pivot chain's MFMAs and
+            // VALU ops never queue behind update MFMAs (measured: 5450 → 3980 cycles per 16-column chain).
             const int jp = jb - 1, tp = 7 - jp;
             const int T = tp * (tp + 1) / 2;
             constexpr int U = 2;
-            for (int q0 = wave; q0 < T; q0 += U * (NW - 1)) {   // waves 1..15 cover tile indices 1..T-1
+            constexpr int NUPD = NW - NW / 4;                   // 12 update waves
+            const int uw = wave - 1 - (wave >> 2);              // 0..11
+            for (int q0 = 1 + uw; q0 < T; q0 += U * NUPD) {     // update waves cover tile indices 1..T-1
                 int ti[U], tj[U];
                 bool ok[U];
                 v4d cr[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int qq = q0 + (NW - 1) * u;
+                    const int qq = q0 + NUPD * u;
                     ok[u] = qq < T;
                     int a = 0;
                     while ((a + 1) * (a + 2) / 2 <= qq) ++a;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
                 }
             }
         }
-        __syncthreads();                              // barrier 1: L16/E published, block fully updated through panel jb-1
+        lds_barrier();                                // barrier 1: L16/E published, block fully updated through panel jb-1
         if (t == 0) break;
         // ---------------- phase B: row tiles  P = X · inv(L16)^T ----------------
         if (wave >= 1 && wave <= t) {
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) D[(jb * 16 + q + 4 * i) * LDD + tr * 16 + r16] = P[i];
         }
-        __syncthreads();                              // barrier 2: panel jb final
+        lds_barrier();                                // barrier 2: panel jb final
         // ---------------- phase C (wave 0): next diagonal tile only ----------------
         if (wave == 0) {
             const int tn = jb + 1;
