@@ -41,6 +41,15 @@ __device__ __forceinline__ double rsqrt_refined(double p) {
     return __builtin_fma(y * e, c, y);
 }
 
+// 1/p to ~1 ulp: v_rcp_f64 seed (relative error e0 <~ 2^-23) + one cubically convergent correction
+// y(1 + e + e²), e = 1 - p y  →  error ~ e0³.  Three dependent ops after the seed.
+__device__ __forceinline__ double rcp_refined(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, y, 1.0);
+    double t = __builtin_fma(e, e, e);
+    return __builtin_fma(y, t, y);
+}
+
 // Radial profile of the base kernel on the SQUARED scaled distance.
 // KernelFunctions.jl Matern32Kernel / Matern52Kernel / SqExponentialKernel.
 __device__ __forceinline__ double kappa_r2(int kern, double r2) {

@@ -37,44 +37,46 @@ constexpr int DIAG_THREADS = 1024;   // 16 waves = 4 per SIMD: single-wave fp64 
 //
 // chol16_with_inverse: factor the symmetric-filled tile S in place (lower part = L16) and carry the
 // identity tile E through the same column operations, which leaves E = L16^{-T} (so inv(L16) comes
-// out of the factorisation itself).  Each 4-column micro-panel is finished with lane shuffles
-// (pivot broadcast by v_readlane), then ONE rank-4 MFMA per tile updates the remaining columns.
+// out of the factorisation itself).  This runs on ONE wave, and a lone wave pays ≈12 cycles per fp64
+// VALU instruction and ≈5 per 32-bit one whether or not they depend on each other — so the code
+// minimises the instruction COUNT per column: the column's entries reach the lanes that need them by
+// three ds_bpermute (issued before the 1/sqrt(p) refinement, which hides their latency) instead of
+// v_readlane/select chains, the update is one unconditional fma per tile with a pre-masked factor,
+// and the scaling of the finished columns is deferred to the end of the 4-column micro-panel.  Then
+// ONE rank-4 MFMA per tile updates the remaining columns.
 __device__ __forceinline__ void chol16_with_inverse(v4d& S, v4d& E, int lane, int col0, int& fail) {
     const int r16 = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) E[i] = (r16 == q + 4 * i) ? 1.0 : 0.0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        double rs[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double p = readlane_f64(S[t], 16 * j + 4 * t + j);
+            double lS = 0.0, lE = 0.0, lc = 0.0;
+            if (j < 3) {
+                // column j is still UNSCALED (= L(:,j)·sqrt(p)):  X(r,c) -= X(r,j)·S(c,j) / p  for the columns c > j
+                lS = __shfl(S[t], 16 * j + r16);            // S(r, j): same row, column j
+                lE = __shfl(E[t], 16 * j + r16);
+                lc = __shfl(S[t], 16 * j + 4 * t + q);      // S(c, j) for this lane's own column c = 4t+q
+            }
             if (!(p > 0.0)) {                      // NaN or non-positive pivot: not PD
                 if (fail < 0) fail = col0 + 4 * t + j;
                 p = 1.0;
             }
             const double inv = rsqrt_refined(p);
-            const bool colj = (q == j);
-            S[t] = colj ? S[t] * inv : S[t];
-            E[t] = colj ? E[t] * inv : E[t];
+            rs[j] = inv;
             if (j < 3) {
-                const int src = 16 * j + r16;          // same row, column j of the micro-panel
-                // (v_permlane16_swap + v_permlane32_swap can do this row broadcast on the VALU, but measured
-                //  slower here than the ds_bpermute round trip: 30.8 vs 27.1 µs per block)
-                const double lS = __shfl(S[t], src), lE = __shfl(E[t], src);
-                double lc = readlane_f64(S[t], 16 * j + 4 * t + j + 1);
-                if (j < 2) {
-                    const double lc2 = readlane_f64(S[t], 16 * j + 4 * t + j + 2);
-                    lc = (q == j + 2) ? lc2 : lc;
-                }
-                if (j < 1) {
-                    const double lc3 = readlane_f64(S[t], 16 * j + 4 * t + j + 3);
-                    lc = (q == j + 3) ? lc3 : lc;
-                }
-                const bool upd = q > j;
-                S[t] = upd ? __builtin_fma(-lS, lc, S[t]) : S[t];
-                E[t] = upd ? __builtin_fma(-lE, lc, E[t]) : E[t];
+                const double lcm = (q > j) ? lc : 0.0;
+                const double m = lcm * (inv * inv);
+                S[t] = __builtin_fma(-lS, m, S[t]);
+                E[t] = __builtin_fma(-lE, m, E[t]);
             }
         }
+        const double sc = (q == 0) ? rs[0] : (q == 1) ? rs[1] : (q == 2) ? rs[2] : rs[3];
+        S[t] *= sc;
+        E[t] *= sc;
         if (t < 3) {
             // rank-4 update of columns > 4t+3:  X(r,c) -= Σ_k X(r,4t+k) · S(c,4t+k)
             const double am = (r16 > 4 * t + 3) ? -S[t] : 0.0;
