@@ -120,12 +120,19 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
 
     int fail = -1;
     v4d S = {0.0, 0.0, 0.0, 0.0};
+    // loop-invariant per-lane LDS offsets of a diagonal tile relative to its corner (the pivot-chain
+    // wave pays ≈5 cycles per integer instruction too): symmetric-fill source, plain element, E slot
+    int osym[4], oel[4], oes[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = q + 4 * i;
+        osym[i] = (r16 >= c) ? (c * LDD + r16) : (r16 * LDD + c);
+        oel[i] = c * LDD + r16;
+        oes[i] = r16 * 16 + c;
+    }
     if (wave == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                 // symmetric fill of diagonal tile 0 from its lower part
-            const int c = q + 4 * i;
-            S[i] = D[(r16 >= c) ? (c * LDD + r16) : (r16 * LDD + c)];
-        }
+        for (int i = 0; i < 4; ++i) S[i] = D[osym[i]];   // symmetric fill of diagonal tile 0 from its lower part
     }
     for (int jb = 0; jb < 8; ++jb) {
         const int t = 7 - jb;                         // row tiles below the diagonal tile
@@ -133,12 +140,11 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
         if (wave == 0) {
             v4d E;
             chol16_with_inverse(S, E, lane, k * BLK + jb * 16, fail);
+            double* Dt = D + jb * 16 * (LDD + 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int c = q + 4 * i;
-                if (r16 >= c) D[(jb * 16 + c) * LDD + jb * 16 + r16] = S[i];
-                Es[r16 * 16 + c] = E[i];                                  // E(row r16, col c)
-                inv16[jb * 256 + r16 * 16 + c] = E[i];                    // inv(L16)(c, r16) = E(r16, c)
+                Dt[oel[i]] = S[i];                    // whole tile: its strict upper part is scratch nobody reads
+                Es[oes[i]] = E[i];                    // E(row r16, col c) = inv(L16)(c, r16)
             }
         } else if (jb > 0 && (wave & 3) != 0) {
             // rest of the rank-16 update with panel jb-1 (tile (jb,jb) was done by wave 0 in phase C).
@@ -187,10 +193,37 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
             }
         }
         lds_barrier();                                // barrier 1: L16/E published, block fully updated through panel jb-1
+        if (wave == 4) {                              // idle partner of the pivot-chain wave: inv(L16_jb) to global for it
+#pragma unroll
+            for (int i = 0; i < 4; ++i) inv16[jb * 256 + lane + 64 * i] = Es[lane + 64 * i];
+        }
         if (t == 0) break;
         // ---------------- phase B: row tiles  P = X · inv(L16)^T ----------------
-        if (wave >= 1 && wave <= t) {
-            const int tr = jb + wave;
+        if (wave == 0) {
+            // The pivot-chain wave owns the first row tile P(jb+1, jb) and applies it to the NEXT diagonal
+            // tile right away, so the next 16-column chain starts right behind barrier 2 (no separate
+            // phase C).  P stays in registers for that update: register s of the MFMA result is
+            // P(r, k = q + 4s), a valid k-slice for both operands of S -= P P^T.
+            const int tn = jb + 1;
+            v4d P = {0.0, 0.0, 0.0, 0.0};
+            const double* Dx = D + jb * 16 * LDD + tn * 16;
+            const int oa = q * 16 + r16;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double aop = Es[oa + 64 * s4];                 // inv(L16)(c = r16, k = 4s+q)
+                const double bop = Dx[oel[s4]];                      // X(r16, k = q+4s)
+                P = mfma_f64(aop, bop, P);
+            }
+            const double* Dn = D + tn * 16 * (LDD + 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S[i] = Dn[osym[i]];
+            double* Dp = D + jb * 16 * LDD + tn * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Dp[oel[i]] = P[i];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) S = mfma_f64(-P[s4], P[s4], S);
+        } else if (wave < t) {
+            const int tr = jb + 1 + wave;              // waves 1..t-1 take the row tiles below wave 0's
             v4d P = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
@@ -202,20 +235,6 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
             for (int i = 0; i < 4; ++i) D[(jb * 16 + q + 4 * i) * LDD + tr * 16 + r16] = P[i];
         }
         lds_barrier();                                // barrier 2: panel jb final
-        // ---------------- phase C (wave 0): next diagonal tile only ----------------
-        if (wave == 0) {
-            const int tn = jb + 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = q + 4 * i;
-                S[i] = D[(r16 >= c) ? ((tn * 16 + c) * LDD + tn * 16 + r16) : ((tn * 16 + r16) * LDD + tn * 16 + c)];
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const double pf = D[(jb * 16 + 4 * s4 + q) * LDD + tn * 16 + r16];
-                S = mfma_f64(-pf, pf, S);
-            }
-        }
     }
     if (wave == 0 && lane == 0 && fail >= 0) {
         if (info[blockIdx.z] == 0) info[blockIdx.z] = fail + 1;

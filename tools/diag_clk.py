@@ -13,6 +13,6 @@ lib.boss_debug_diag_clk.argtypes = [C.POINTER(C.c_ulonglong)]
 lib.boss_debug_diag_clk(buf)
 t = np.array(buf[:], dtype=np.float64)
 t = t[t > 0]
-d = np.diff(t) * 10.0   # s_memtime ticks at 100 MHz -> ns
-print("events:", len(t), " total %.1f us" % ((t[-1] - t[0]) / 100.0))
-print("deltas (ns):", " ".join(f"{x:.0f}" for x in d))
+d = np.diff(t)   # s_memtime ticks = shader cycles
+print("events:", len(t), " total cycles %.0f" % (t[-1] - t[0]))
+print("deltas (cycles):", " ".join(f"{x:.0f}" for x in d))
