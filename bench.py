@@ -49,13 +49,20 @@ def flops_acq_eval(N, d):
     return N ** 2 + N * (3 * d + 20) + 4 * N
 
 
+PMC_SUMMARY = None
+
+
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_pmc_summary.json): FETCH_SIZE (KB, doubled — on gfx950 it reports half the bytes of
-    16-B/lane streaming reads, MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KB)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    (the newest profiles/*_pmc_summary.json, written by tools/pmc_summary.py): FETCH_SIZE (KB, doubled —
+    on gfx950 it reports half the bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md §HBM) +
+    WRITE_SIZE (KB)."""
+    global PMC_SUMMARY
+    import glob
     try:
-        d = json.load(open(path))
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+        PMC_SUMMARY = os.path.relpath(paths[-1], ROOT)
+        d = json.load(open(paths[-1]))
         for k, v in d.items():
             if kernel_substr in k:
                 return (2.0 * v["fetch_kb_raw"] + v["write_kb"]) * 1024.0
@@ -197,7 +204,7 @@ def main():
         ach = fl_pred / (ms_pred / n_pred * 1e-3) / 1e12
         roof = {"kernel": "predict_kernel", "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("predict_kernel"),
-                "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 16-B/lane correction] + WRITE_SIZE, x1024; profiles/r01_pmc_summary.json)",
+                "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 16-B/lane correction] + WRITE_SIZE, x1024; %s)" % PMC_SUMMARY,
                 "avg_launch_ms": ms_pred / n_pred, "flops_per_launch": fl_pred}
         # the factorisation: N^3/3 over the whole posterior update (two-stream look-ahead; the
         # per-class event times below come from the serialised profiling pass)
