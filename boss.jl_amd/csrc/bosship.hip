@@ -212,6 +212,43 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
                           size_t inv16_bstride, int* info) {
     const int nblk = Np / BLK;
     hipStream_t s = c->stream;
+    static const int pair_min_batch = getenv("BOSS_PAIR_MIN_BATCH") ? atoi(getenv("BOSS_PAIR_MIN_BATCH")) : 4;
+    if (batch >= pair_min_batch && nblk >= 3) {
+        // Batched factorisations have parallelism to spare and are bound by the HBM traffic of the
+        // trailing updates (every step reads and writes the whole trailing matrix).  Pair the panels:
+        //   diag_k, solve_k, column k+1 <- panel k, diag_{k+1}, solve_{k+1}, trailing(>= k+2) <- panels k,k+1 (K = 256)
+        // so each trailing tile moves through HBM half as often.  One stream, no events.
+        for (int k = 0; k < nblk; k += 2) {
+            for (int kk = k; kk < k + 2 && kk < nblk; ++kk) {
+                {
+                    ProfScope ps(c, "potrf_diag");
+                    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, batch), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, A, ld, bstride,
+                                       kk, inv16, inv16_bstride, info);
+                }
+                const int nrows16 = (Np - (kk + 1) * BLK) / 16 + 1;
+                {
+                    ProfScope ps(c, "potrf_trsm");
+                    hipLaunchKernelGGL(potrf_trsm_kernel, dim3(nrows16, 1, batch), dim3(64), 0, s, A, ld, bstride, kk, inv16,
+                                       inv16_bstride, (kk + 1) * BLK);
+                }
+                const int m = nblk - 1 - kk;
+                if (kk == k && m > 0) {
+                    ProfScope ps(c, "potrf_syrk");
+                    hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, kk, m, 1);
+                }
+            }
+            const int m2 = nblk - (k + 2);                   // block triangle behind the pair
+            if (m2 > 0) {
+                ProfScope ps(c, "potrf_syrk");
+                hipLaunchKernelGGL(potrf_syrk_kernel, dim3((m2 * (m2 + 1) / 2 + m2) * batch, 1, 1), dim3(256), 0, s, A, ld, bstride,
+                                   k, k + 2, m2, 2, batch);
+            } else if (m2 == 0 && k + 1 < nblk) {
+                // the pair ends the matrix: only the δ^T rows behind it are left (their solve rides in solve_{k+1},
+                // but panel k's contribution to the δ^T entries of block column k+1 was applied by colupd) — nothing to do
+            }
+        }
+        return;
+    }
     // Look-ahead needs no profiling scopes (they would serialise the two streams) and >= 3 blocks.
     const bool la = c->lookahead && !c->prof_on && nblk >= 3;
     if (la) {
@@ -252,7 +289,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         if (!la) {
             ProfScope ps(c, "potrf_syrk");
             hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m * (m + 1) / 2 + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
-                               k + 1, m);
+                               k + 1, m, 1, 0);
             continue;
         }
         // ---- look-ahead: panel chain on `s`, bulk of the trailing update on the side stream ----------
@@ -269,7 +306,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
             (void)hipStreamWaitEvent(c->side_stream, c->ev_panel[k], 0);
             if (exp_norest != 2)
                 hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m2 * (m2 + 1) / 2 + m2, 1, batch), dim3(256), 0, c->side_stream, A,
-                                   ld, bstride, k, k + 2, m2);
+                                   ld, bstride, k, k + 2, m2, 1, 0);
             (void)hipEventRecord(c->ev_rest[k], c->side_stream);
             last_rest = k;
         }

@@ -338,7 +338,7 @@ constexpr int SYRK_LDS_BYTES = 0;
 // acc is INITIALISED from C (its load latency overlaps the operand prologue), updated with
 // acc -= P_i P_j^T, and stored back: the epilogue is pure stores.
 template <class G>
-__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k, int R0, int C0) {
+__device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k, int R0, int C0, int K = BLK) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / G::WC, wc = wave % G::WC;
     const double* Pi = A + R0 + (size_t)k * BLK * ld;
@@ -356,7 +356,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k,
                 acc[m][n][i] = c2[0];
                 acc[m + 1][n][i] = c2[1];
             }
-    G::template run<-1>(Pi, ld, Pj, ld, BLK, acc);
+    G::template run<-1>(Pi, ld, Pj, ld, K, acc);
 #pragma unroll
     for (int m = 0; m < G::TM; m += 2)
 #pragma unroll
@@ -375,19 +375,32 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k,
 //   potrf_colupd_kernel only block column k+1 (the next panel), 32×128 tiles so that this short
 //                       kernel on the critical path is one small round.
 __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                            int first, int m) {
-    double* A = Abase + (size_t)blockIdx.z * bstride;
-    const int t = blockIdx.x;
+                                                            int first, int m, int npan, int batch1d) {
+    // npan adjacent panels k..k+npan-1 applied in one pass (K = 128·npan): the batched schedule pairs
+    // panels so every trailing tile is read and written half as often.
+    // batch1d > 0: the whole batch is ONE 1-D grid (tiles of matrix 0, then of matrix 1, ...) and
+    // workgroup ids are permuted so that each XCD — workgroups are dealt round-robin over the 8 XCDs,
+    // ≈64 resident per XCD — works on 64 CONSECUTIVE tiles of that list (a couple of block rows of one
+    // matrix) instead of every 8th: its L2 then holds a handful of panel blocks rather than all of them.
     const int nsq = m * (m + 1) / 2;
+    int t = blockIdx.x, b = blockIdx.z;
+    if (batch1d > 0) {
+        const int Tb = nsq + m, total = Tb * batch1d;
+        const int L = blockIdx.x;
+        const int idx = (L < (total & ~511)) ? ((L & ~511) + (L & 7) * 64 + ((L >> 3) & 63)) : L;
+        b = idx / Tb;
+        t = idx - b * Tb;
+    }
+    double* A = Abase + (size_t)b * bstride;
     if (t < nsq) {
         int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
         while ((i + 1) * (i + 2) / 2 <= t) ++i;
         while (i * (i + 1) / 2 > t) --i;
         int j = t - i * (i + 1) / 2;
-        syrk_tile<SyrkG>(A, ld, k, (first + i) * BLK, (first + j) * BLK);
+        syrk_tile<SyrkG>(A, ld, k, (first + i) * BLK, (first + j) * BLK, npan * BLK);
     } else {
         int j = t - nsq;
-        syrk_tile<RhsG>(A, ld, k, (first + m) * BLK, (first + j) * BLK);
+        syrk_tile<RhsG>(A, ld, k, (first + m) * BLK, (first + j) * BLK, npan * BLK);
     }
 }
 

@@ -120,6 +120,29 @@ def batch_cfg(S=512, N=1024, d=8):
     print(f"loglike_batch S={S} N={N}: first {t1*1e3:.1f} ms, steady {dt*1e3:.1f} ms  ({S/dt:.0f} factorizations/s, {fl/dt/1e12:.2f} TF)  rel err {err:.1e} ok={int((st==0).sum())}", flush=True)
 
 
+def batch_big(N=4096, d=8):
+    """Batched posterior updates at the BASELINE size: S hyper-parameter sets on the same data."""
+    X, y, _ = problem(d, N, 1)
+    rng = np.random.default_rng(5)
+    for S in (8, 32):
+        lam = np.exp(-0.7 + 0.1 * rng.standard_normal((d, S)))
+        amp = np.exp(0.1 * rng.standard_normal(S))
+        sig = np.full(S, 0.05)
+        api.loglike_batch(X, y, "matern52", lam, amp, sig)
+        t = time.time()
+        ll, st = api.loglike_batch(X, y, "matern52", lam, amp, sig)
+        dt = time.time() - t
+        want = O.gp_data_loglike_slice(X, y, "matern52", lam[:, S - 1], amp[S - 1], sig[S - 1])
+        print(f"loglike_batch S={S} N={N}: {dt*1e3:.1f} ms  ({S/dt:.0f} updates/s, {S*N**3/3/dt/1e12:.1f} TF)  rel err {abs(ll[S-1]-want)/(1+abs(want)):.1e} ok={int((st==0).sum())}", flush=True)
+        api.prof_enable(0, True)
+        api.prof_reset(0)
+        api.loglike_batch(X, y, "matern52", lam, amp, sig)
+        for k in ("gram", "potrf_diag", "potrf_trsm", "potrf_syrk", "logdet"):
+            ms, n = api.prof_get(0, k)
+            print(f"   {k:12s} {ms:8.3f} ms over {n} launches", flush=True)
+        api.prof_enable(0, False)
+
+
 def multi_output(N=2048, d=6, M=8192):
     """BASELINE config 4: 2 constrained outputs, parametric mean, N=2048 d=6."""
     rng = np.random.default_rng(3)
@@ -163,5 +186,7 @@ if __name__ == "__main__":
         append_timing()
     if "batch" in stages:
         batch_cfg()
+    if "batch_big" in stages:
+        batch_big()
     if "multi" in stages:
         multi_output()
