@@ -560,6 +560,67 @@ def test_sequential_batch_am_matches_refit_loop(api, O):
         Yo = np.hstack([Yo, yhat[:, None]])
 
 
+@pytest.mark.parametrize("d,N,M", [(17, 150, 40), (33, 257, 65), (8, 511, 33), (8, 513, 32)])
+def test_wide_inputs_and_step_boundaries(api, O, d, N, M):
+    """Input dimensions beyond one 16-wide staging chunk of the Gram kernel, and N just below / above
+    the 256-row prediction steps (padding rows must behave as identity)."""
+    rng = np.random.default_rng(d * 1000 + N)
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(X).sum(0) / np.sqrt(d) + 0.05 * rng.standard_normal(N)
+    Xs = rng.uniform(0, 1, (d, M))
+    lam = rng.uniform(0.8, 1.6, d)
+    g = api.GP(X, y, "matern32")
+    lp = g.update(lam, 0.9, 0.07)
+    post = O.gp_fit(X, y, "matern32", lam, 0.9, 0.07)
+    assert abs(lp - post.logpdf) <= 1e-10 * (1 + abs(post.logpdf))
+    mu, var = g.predict(Xs)
+    mu_o, var_o = O.gp_mean_and_var(post, Xs)
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+    g.close()
+
+
+def test_two_host_threads_share_a_device(api, O):
+    """The reference calls its closures from Threads.@threads regions (optim_multistart.jl:61-90):
+    two host threads drive two different handles on the same device at the same time."""
+    import threading
+    rng = np.random.default_rng(99)
+    d, N, M = 4, 300, 96
+    data = []
+    for t in range(2):
+        X = rng.uniform(0, 1, (d, N))
+        y = np.cos(3 * X).sum(0)
+        data.append((X, y, rng.uniform(0, 1, (d, M))))
+    errs = []
+
+    def work(t):
+        try:
+            X, y, Xs = data[t]
+            g = api.GP(X, y, "matern52")
+            cand = api.Candidates(Xs)
+            for it in range(6):
+                lam = np.full(d, 0.4 + 0.05 * it + 0.1 * t)
+                lp = g.update(lam, 1.0, 0.05)
+                post = O.gp_fit(X, y, "matern52", lam, 1.0, 0.05)
+                assert abs(lp - post.logpdf) <= 1e-10 * (1 + abs(post.logpdf))
+                acq, am, mx = api.acq_ei([[g]], cand, [1.0], None, float(y.max()))
+                want = O.ei_acquisition([post], Xs, [1.0], None, float(y.max()))
+                assert np.allclose(acq, want, rtol=0, atol=1e-12) and am == int(np.argmax(want))
+                mu, var = g.predict(Xs)
+                mu_o, var_o = O.gp_mean_and_var(post, Xs)
+                assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+            g.close()
+        except Exception as e:  # pragma: no cover
+            import traceback
+            errs.append(traceback.format_exc())
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[0]
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
