@@ -43,6 +43,8 @@ SIGNATURES = {
     "boss_gp_loglike_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
                                         C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
     "boss_gp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
+    "boss_gp_predict_grad": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
+                                       C.POINTER(C.c_long)]),
     "boss_gp_predict_cov": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_cand_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.POINTER(C.c_void_p)]),
     "boss_cand_free": (None, [C.c_void_p]),
@@ -50,6 +52,8 @@ SIGNATURES = {
                               C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
     "boss_acq_ei_moments": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
                                       C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_acq_ei_grad": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
+                                   C.c_double, _c_ucp, _c_dp, _c_dp]),
     "boss_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _c_dp]),
     "boss_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "boss_prof_reset": (C.c_int, [C.c_int]),
@@ -234,6 +238,31 @@ class GP:
         _check(rc)
         return mu, var
 
+    def predict_grad(self, Xs, mean_Xs=None, mean_grad=None):
+        """mean_and_var(post, X) and its gradient w.r.t. the candidates: returns
+        (mu[M], var[M], dmu[d,M], dvar[d,M]) — analytic, evaluated on the device."""
+        Xs = _f64(Xs)
+        if Xs.ndim == 1:
+            Xs = _f64(Xs.reshape(-1, 1))
+        if Xs.shape[0] != self.d:
+            raise ValueError("candidates must be d×M")
+        M = Xs.shape[1]
+        ms = None if mean_Xs is None else _f64(np.asarray(mean_Xs).reshape(-1), 1)
+        mg = None if mean_grad is None else _f64(mean_grad, 2)
+        if mg is not None and mg.shape != (self.d, M):
+            raise ValueError("mean_grad must be d×M")
+        mu, var = np.zeros(M), np.zeros(M)
+        dmu, dvar = np.zeros((self.d, M), order="F"), np.zeros((self.d, M), order="F")
+        bad = C.c_long(-1)
+        rc = load_library().boss_gp_predict_grad(self._h, M, _dp(Xs), _dp(ms), _dp(mg), _dp(mu), _dp(var), _dp(dmu),
+                                                 _dp(dvar), C.byref(bad))
+        if rc == BOSS_E_NEG_VAR:
+            e = DomainError(rc, load_library().boss_last_error().decode())
+            e.bad_index = bad.value
+            raise e
+        _check(rc)
+        return mu, var, dmu, dvar
+
     def predict_cov(self, Xs, mean_Xs=None):
         """mean_and_cov(post, X::Matrix): returns (mu[M], cov[M,M]) with the diagonal clipped."""
         Xs = _f64(Xs, 2)
@@ -362,6 +391,31 @@ def acq_ei(gps: Sequence[Sequence[GP]], cand: Candidates, fit_coefs, y_max=None,
                                       0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am),
                                       C.byref(mx)))
     return acq, am.value, mx.value
+
+
+def acq_ei_grad(gps: Sequence[GP], Xs, fit_coefs, y_max=None, best=None, valid_mask=None, mean_Xs=None, mean_grad=None):
+    """EI·feas and its gradient w.r.t. the candidates for one hyper-parameter sample.  gps[p] = output p.
+    mean_Xs: None or [P][M]; mean_grad: None or [P][d][M].  Returns (acq[M], dacq[d, M])."""
+    P = len(gps)
+    Xs = _f64(Xs, 2)
+    d, M = Xs.shape
+    arr = (C.c_void_p * P)()
+    for p in range(P):
+        arr[p] = gps[p]._h
+    coefs = _f64(np.asarray(fit_coefs).reshape(-1), 1)
+    ym = None if y_max is None else _f64(np.asarray(y_max).reshape(-1), 1)
+    mask = None if valid_mask is None else np.ascontiguousarray(np.asarray(valid_mask, dtype=bool).astype(np.uint8))
+    ms = None if mean_Xs is None else np.ascontiguousarray(np.asarray(mean_Xs, dtype=np.float64).reshape(P, M))
+    mg = None
+    if mean_grad is not None:
+        a = np.asarray(mean_grad, dtype=np.float64).reshape(P, d, M)
+        mg = np.ascontiguousarray(a.transpose(0, 2, 1))           # [p][j*d + m]
+    acq = np.zeros(M)
+    dacq = np.zeros((d, M), order="F")
+    _check(load_library().boss_acq_ei_grad(P, arr, M, _dp(Xs), _dp(ms), _dp(mg), _dp(coefs), _dp(ym),
+                                           0 if best is None else 1, 0.0 if best is None else float(best), _ucp(mask),
+                                           _dp(acq), _dp(dacq)))
+    return acq, dacq
 
 
 def acq_ei_moments(mu, var, fit_coefs, y_max=None, best=None, valid_mask=None, device: int = 0):

@@ -100,6 +100,9 @@ static int get_ctx(int device, Ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)backsolve_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG64>::BYTES));
     g_ctx[device] = c;
@@ -151,6 +154,8 @@ struct boss_gp {
     Ctx* ctx = nullptr;
     int kernel = 0, d = 0, N = 0, Np = 0, nblk = 0, ld = 0;
     double *Xraw = nullptr, *Xsc = nullptr, *y = nullptr, *mean = nullptr, *A = nullptr;
+    double *LT = nullptr, *DT2 = nullptr, *avec = nullptr;   // gradients: transposed factor, transposed 256×256 inverses, a = L⁻ᵀz (lazily)
+    bool have_lt = false;
     double *inv16 = nullptr, *Dinv = nullptr, *Dinv2 = nullptr, *hyp = nullptr, *invlam = nullptr, *scal = nullptr;
     int* info = nullptr;
     unsigned char* discrete_dev = nullptr;     // d flags (device) or null
@@ -328,7 +333,7 @@ static void gram_enqueue(Ctx* c, const double* Xsc, size_t xs_bstride, int d, in
 static void gp_release(boss_gp* g) {
     if (!g) return;
     if (g->ctx) (void)hipSetDevice(g->ctx->device);
-    void* ptrs[] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->Dinv2, g->hyp, g->invlam, g->scal, g->info, g->discrete_dev};
+    void* ptrs[] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->Dinv2, g->LT, g->DT2, g->avec, g->hyp, g->invlam, g->scal, g->info, g->discrete_dev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_res) (void)hipHostFree(g->host_res);
@@ -532,6 +537,7 @@ extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double am
     hipStream_t s = c->stream;
     g->fitted = false;
     g->have_dinv = false;
+    g->have_lt = false;
     // +1e-8 on every parameter (gaussian_process.jl:239-241)
     HIPCHK(hipEventSynchronize(g->par_ev));   // previous update's staging copies have been consumed
     double* invlam = g->host_par;
@@ -611,11 +617,16 @@ static int gp_grow(boss_gp* g, int Nnew) {
     HIPCHK(hipStreamSynchronize(s));
     double* old[8] = {g->Xraw, g->Xsc, g->y, g->mean, g->A, g->inv16, g->Dinv, g->Dinv2};
     for (double* p : old) (void)hipFree(p);
+    if (g->LT) (void)hipFree(g->LT);
+    if (g->DT2) (void)hipFree(g->DT2);
+    if (g->avec) (void)hipFree(g->avec);
+    g->LT = g->DT2 = g->avec = nullptr;
     g->Xraw = nw[0]; g->Xsc = nw[1]; g->y = nw[2]; g->mean = nw[3]; g->A = nw[4]; g->inv16 = nw[5]; g->Dinv = nw[6]; g->Dinv2 = nw[7];
     g->Np = Np2;
     g->nblk = nblk2;
     g->ld = ld2;
     g->have_dinv = false;
+    g->have_lt = false;
     return BOSS_OK;
 }
 
@@ -636,6 +647,7 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
     if (rc) return rc;
     g->fitted = false;
     g->have_dinv = false;
+    g->have_lt = false;
     {
         std::vector<double> xb;
         pack_points(xb, X_new, d, n, n, g->discrete.empty() ? nullptr : g->discrete.data());
@@ -903,7 +915,8 @@ __global__ void scale_cand_kernel(const double* __restrict__ Craw, double* __res
 }
 
 // enqueue μ/σ² (unclipped) of one posterior at resident candidates into device arrays mu, var (length ≥ M)
-static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_dev, double* mu, double* var) {
+static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_dev, double* mu, double* var,
+                           bool for_grad = false) {
     Ctx* c = g->ctx;
     hipStream_t s = c->stream;
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
@@ -918,7 +931,8 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     const int Mp = cd->Mp;
     // 64 candidates per workgroup once that still fills the machine (BOSS_FORCE_BN64=1: tests)
     static const bool force64 = getenv("BOSS_FORCE_BN64") && atoi(getenv("BOSS_FORCE_BN64"));
-    const int BN = (cd->M >= 64 * 256 || force64) ? 64 : 32;
+    // the gradient pass (adjoint substitution) runs on 32-candidate slabs
+    const int BN = for_grad ? 32 : ((cd->M >= 64 * 256 || force64) ? 64 : 32);
     const int tiles = (cd->M + BN - 1) / BN;
     int rc = ws_reserve(c->csc, sizeof(double) * (size_t)g->d * Mp);
     if (rc) return rc;
@@ -990,6 +1004,199 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
         std::snprintf(msg, sizeof msg, "The posterior GP predicted variance %g but only values above -1e-08 are tolerated. (DomainError)", var[bad]);
         return fail(BOSS_E_NEG_VAR, msg);
     }
+    return BOSS_OK;
+}
+
+static int ei_params(Ctx* c, hipStream_t s, int P, const double* fit_coefs, const double* y_max, int has_best, double best,
+                     EiPar* par, double* dcoef, double* dymax);
+
+// SURVEY §8f3.  Enqueue μ, σ² (unclipped) and ∇μ, ∇σ² of one posterior at resident candidates:
+// forward substitution (prediction kernel, 32-wide V slabs), adjoint substitution in place, gradient
+// accumulation.  The transposed factor, the transposed 256×256 inverses and a = L⁻ᵀz are built once
+// per factorisation.  mean_s_dev / mean_grad_dev may be null.
+static int grad_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_dev, const double* mean_grad_dev, double* mu,
+                        double* var, double* dmu, double* dvar) {
+    Ctx* c = g->ctx;
+    hipStream_t s = c->stream;
+    const int d = g->d, Np = g->Np, M = cd->M;
+    const size_t glds = sizeof(double) * ((size_t)d * GRAD_CHUNK + GRAD_CHUNK + 8 * 2 * (GRAD_MAX_D + 1) * 32);
+    if (glds > 150 * 1024) return fail(BOSS_E_INVALID, "x_dim too large for the gradient kernel's LDS staging");
+    if (!g->LT) {
+        if (hipMalloc((void**)&g->LT, sizeof(double) * (size_t)g->ld * Np) != hipSuccess ||
+            hipMalloc((void**)&g->DT2, sizeof(double) * (size_t)Np * PRED_RB) != hipSuccess ||
+            hipMalloc((void**)&g->avec, sizeof(double) * (size_t)Np * 2) != hipSuccess) {
+            if (g->LT) (void)hipFree(g->LT);
+            if (g->DT2) (void)hipFree(g->DT2);
+            g->LT = g->DT2 = g->avec = nullptr;
+            (void)hipGetLastError();
+            return fail(BOSS_E_ALLOC, "device allocation failed (transposed factor)");
+        }
+        g->have_lt = false;
+    }
+    int rc = predict_enqueue(g, cd, mean_s_dev, mu, var, true);    // V slabs (32 wide) + scaled candidates
+    if (rc) return rc;
+    if (!g->have_lt) {                                      // once per factorisation
+        hipLaunchKernelGGL(transpose_kernel, dim3(Np / 64, Np / 64, 1), dim3(256), 0, s, (const double*)g->A, g->ld, (size_t)0,
+                           g->LT, g->ld, (size_t)0, Np);            // same (non power-of-two) leading dimension as the factor
+        hipLaunchKernelGGL(transpose_kernel, dim3(PRED_RB / 64, PRED_RB / 64, Np / PRED_RB), dim3(256), 0, s,
+                           (const double*)g->Dinv2, PRED_RB, (size_t)PRED_RB * PRED_RB, g->DT2, PRED_RB,
+                           (size_t)PRED_RB * PRED_RB, PRED_RB);
+        // a = L⁻ᵀ z: 256-row steps from the last to the first (GEMV partials live in the second half of avec's buffer)
+        const int nb = Np / PRED_RB;
+        double* partial = g->avec + Np;                      // [<= nb-1][256] fits: (nb-1)*256 < Np
+        for (int ib = nb - 1; ib >= 0; --ib) {
+            const int nch = nb - 1 - ib;
+            if (nch > 0)
+                hipLaunchKernelGGL(bt_gemv_partial_kernel, dim3(nch), dim3(256), 0, s, (const double*)g->LT, g->ld, ib,
+                                   (const double*)g->avec, partial);
+            hipLaunchKernelGGL(bt_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)g->A, g->ld, Np, g->N, ib, nch,
+                               (const double*)partial, (const double*)g->DT2, g->avec);
+        }
+        g->have_lt = true;
+    }
+    typedef PredG32 G;
+    const int tiles = (M + 31) / 32;
+    double* slabs = (double*)c->vscratch.p;
+    hipLaunchKernelGGL(backsolve_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->LT, g->ld,
+                       Np, (const double*)g->DT2, slabs);
+    hipLaunchKernelGGL(grad_accum_kernel, dim3(tiles), dim3(256), glds, s, (const double*)slabs, (const double*)g->avec, Np, g->N,
+                       (const double*)g->Xsc, (const double*)c->csc.p, d, cd->Mp, M, g->kernel, g->amp2, (const double*)g->invlam,
+                       (const unsigned char*)g->discrete_dev, mean_grad_dev, dmu, dvar);
+    HIPCHK(hipGetLastError());
+    return BOSS_OK;
+}
+
+extern "C" int boss_gp_predict_grad(boss_gp_t* g, int M, const double* Xs, const double* mean_Xs, const double* mean_grad,
+                                    double* mu, double* var, double* dmu, double* dvar, long* bad_index) {
+    if (!g || !Xs || !mu || !var || !dmu || !dvar) return fail(BOSS_E_INVALID, "NULL argument");
+    if (M < 1) return fail(BOSS_E_INVALID, "M must be >= 1");
+    if (bad_index) *bad_index = -1;
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    boss_cand_t* cd = nullptr;
+    int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
+    if (rc) return rc;
+    const int d = g->d;
+    const size_t dm = (size_t)d * M;
+    double* dev = nullptr;   // mu | var | mean | mean_grad | dmu | dvar | bad
+    if (hipMalloc((void**)&dev, sizeof(double) * (3 * (size_t)M + 3 * dm + 2)) != hipSuccess) {
+        boss_cand_free(cd);
+        return fail(BOSS_E_ALLOC, "device allocation failed");
+    }
+    double *dmu_ = dev, *dvar_ = dev + M, *dmean = dev + 2 * (size_t)M, *dmg = dev + 3 * (size_t)M;
+    double *dgm = dmg + dm, *dgv = dgm + dm;
+    unsigned long long* dbad = (unsigned long long*)(dgv + dm);
+    hipStream_t s = c->stream;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(dev);
+        boss_cand_free(cd);
+    };
+    if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * M, hipMemcpyHostToDevice, s);
+    if (mean_grad) (void)hipMemcpyAsync(dmg, mean_grad, sizeof(double) * dm, hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(dbad, 0xff, sizeof(unsigned long long), s);
+    rc = grad_enqueue(g, cd, mean_Xs ? dmean : nullptr, mean_grad ? dmg : nullptr, dmu_, dvar_, dgm, dgv);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    hipLaunchKernelGGL(clip_var_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dvar_, M, dbad);
+    unsigned long long bad = 0;
+    (void)hipMemcpyAsync(mu, dmu_, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(var, dvar_, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(dmu, dgm, sizeof(double) * dm, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(dvar, dgv, sizeof(double) * dm, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    hipError_t e2 = hipGetLastError();
+    cleanup();
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e2));
+    if (bad != ~0ULL) {
+        if (bad_index) *bad_index = (long)bad;
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "The posterior GP predicted variance %g but only values above -1e-08 are tolerated. (DomainError)", var[bad]);
+        return fail(BOSS_E_NEG_VAR, msg);
+    }
+    return BOSS_OK;
+}
+
+// Acquisition value AND gradient w.r.t. the candidates for one hyper-parameter sample (MAP): the EI x feasibility
+// chain rule runs on the device right behind the moment gradients of the P outputs.
+extern "C" int boss_acq_ei_grad(int P, boss_gp_t* const* gps, int M, const double* Xs, const double* mean_Xs,
+                                const double* mean_grad, const double* fit_coefs, const double* y_max, int has_best,
+                                double best, const unsigned char* valid_mask, double* acq_out, double* dacq_out) {
+    if (P < 1 || !gps || M < 1 || !Xs || !fit_coefs || !acq_out || !dacq_out) return fail(BOSS_E_INVALID, "bad arguments");
+    for (int p = 0; p < P; ++p) {
+        if (!gps[p]) return fail(BOSS_E_INVALID, "NULL posterior handle");
+        if (gps[p]->ctx != gps[0]->ctx || gps[p]->d != gps[0]->d)
+            return fail(BOSS_E_INVALID, "all handles must live on one device and share x_dim");
+        if (!gps[p]->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    }
+    Ctx* c = gps[0]->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    const int d = gps[0]->d;
+    boss_cand_t* cd = nullptr;
+    int rc = boss_cand_create(c->device, d, M, Xs, &cd);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const size_t dm = (size_t)d * M;
+    // device scratch: mu[P][M] | var[P][M] | mean[P][M] | mean_grad[P][dM] | dmu[P][dM] | dvar[P][dM] | acq[M] | dacq[dM] | coefs[P] | ymax[P] | mask
+    const size_t nd = (size_t)3 * P * M + (size_t)3 * P * dm + M + dm + 2 * P;
+    double* dev = nullptr;
+    if (hipMalloc((void**)&dev, sizeof(double) * nd + M) != hipSuccess) {
+        boss_cand_free(cd);
+        (void)hipGetLastError();
+        return fail(BOSS_E_ALLOC, "device allocation failed");
+    }
+    double* dmu = dev;
+    double* dvar = dmu + (size_t)P * M;
+    double* dmean = dvar + (size_t)P * M;
+    double* dmg = dmean + (size_t)P * M;
+    double* dgm = dmg + (size_t)P * dm;
+    double* dgv = dgm + (size_t)P * dm;
+    double* dacq = dgv + (size_t)P * dm;
+    double* ddacq = dacq + M;
+    double* dcoef = ddacq + dm;
+    double* dymax = dcoef + P;
+    unsigned char* dmask = (unsigned char*)(dev + nd);
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(dev);
+        boss_cand_free(cd);
+    };
+    EiPar par;
+    rc = ei_params(c, s, P, fit_coefs, y_max, has_best, best, &par, dcoef, dymax);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * P * M, hipMemcpyHostToDevice, s);
+    if (mean_grad) (void)hipMemcpyAsync(dmg, mean_grad, sizeof(double) * P * dm, hipMemcpyHostToDevice, s);
+    if (valid_mask) (void)hipMemcpyAsync(dmask, valid_mask, M, hipMemcpyHostToDevice, s);
+    if (par.mode != 0) {
+        for (int p = 0; p < P; ++p) {
+            rc = grad_enqueue(gps[p], cd, mean_Xs ? dmean + (size_t)p * M : nullptr, mean_grad ? dmg + (size_t)p * dm : nullptr,
+                              dmu + (size_t)p * M, dvar + (size_t)p * M, dgm + (size_t)p * dm, dgv + (size_t)p * dm);
+            if (rc) {
+                cleanup();
+                return rc;
+            }
+        }
+    }
+    hipLaunchKernelGGL(ei_grad_kernel, dim3((M + 127) / 128), dim3(128), 0, s, (const double*)dmu, (const double*)dvar,
+                       (const double*)dgm, (const double*)dgv, M, d, par, (const double*)dcoef, (const double*)dymax,
+                       valid_mask ? (const unsigned char*)dmask : nullptr, dacq, ddacq);
+    (void)hipMemcpyAsync(acq_out, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(dacq_out, ddacq, sizeof(double) * dm, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    hipError_t e2 = hipGetLastError();
+    cleanup();
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e2));
     return BOSS_OK;
 }
 

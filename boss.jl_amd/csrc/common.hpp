@@ -63,6 +63,16 @@ __device__ __forceinline__ double kappa_r2(int kern, double r2) {
     return (1.0 + s + s * s / 3.0) * exp(-s);
 }
 
+// h(r) = κ'(r)/r on the squared scaled distance (finite at r = 0): the radial factor of ∇k,
+// ∇_{x*} k(x, x*) = α² h(r) (x* − x) ⊘ λ².
+__device__ __forceinline__ double kappa_prime_over_r_r2(int kern, double r2) {
+    if (kern == KERN_SQEXP) return -exp(-0.5 * r2);
+    double r = sqrt(r2);
+    if (kern == KERN_MATERN32) return -3.0 * exp(-1.7320508075688772 * r);
+    double s = 2.23606797749979 * r;
+    return -(5.0 / 3.0) * (1.0 + s) * exp(-s);
+}
+
 __device__ __forceinline__ double normcdf_dev(double z) {   // StatsFuns.normcdf = erfc(-z/√2)/2
     return 0.5 * erfc(-z * 0.7071067811865476);
 }

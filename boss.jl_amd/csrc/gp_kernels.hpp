@@ -294,6 +294,212 @@ __global__ __launch_bounds__(256) void dinv_pair_assemble_kernel(const double* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// analytic gradients of the posterior moments w.r.t. the candidates,
+//     ∇μ(x*)  = ∇m(x*) + Σ_i a_i ∇k(x_i, x*),   a = (K+σ²I)⁻¹(y−m) = L⁻ᵀ z
+//     ∇σ²(x*) = −2 Σ_i w_i ∇k(x_i, x*),           w = (K+σ²I)⁻¹ k* = L⁻ᵀ v
+// (what the reference obtains by pushing ForwardDiff duals through AbstractGPs,
+//  src/acquisition_maximizers/optimization.jl:36,89-118).  The adjoint (backward) substitution
+// W = L⁻ᵀ V runs on the V slabs the prediction kernel left behind, in place, with the same
+// 256-row-step / register-ring machinery on a transposed copy of the factor; `a` is solved once per
+// factorisation by a chain of small GEMV launches.
+// ------------------------------------------------------------------------------------------
+// out[c + r*ldo] = in[r + c*ldi] for an n×n matrix (batched over blockIdx.z with the given strides)
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int ldi, size_t si,
+                                                        double* __restrict__ out, int ldo, size_t so, int n) {
+    __shared__ double t[64][65];
+    const double* I = in + (size_t)blockIdx.z * si;
+    double* O = out + (size_t)blockIdx.z * so;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4)
+        if (r0 + tx < n && c0 + c < n) t[c][tx] = I[(size_t)(c0 + c) * ldi + r0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4)
+        if (c0 + tx < n && r0 + r < n) O[(size_t)(r0 + r) * ldo + c0 + tx] = t[tx][r];
+}
+
+// a = L⁻ᵀ z (= (K+σ²I)⁻¹(y−m)), once per factorisation, in 256-row steps from the last to the first:
+//     bt_gemv_partial_kernel   partial[c][r] = Σ_{k in 256-column chunk c} Lᵀ[i0+r, k] a[k]      (one workgroup per chunk)
+//     bt_finish_kernel         a[i0..i0+255] = Dinv2ᵀ_i (z_i − Σ_c partial[c])                   (fixed summation order)
+__global__ __launch_bounds__(256) void bt_gemv_partial_kernel(const double* __restrict__ LT, int ldt, int ib,
+                                                              const double* __restrict__ a, double* __restrict__ partial) {
+    const int r = threadIdx.x, kc = (ib + 1 + blockIdx.x) * PRED_RB;
+    const double* col = LT + (size_t)ib * PRED_RB + r + (size_t)kc * ldt;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < PRED_RB; ++k) s = __builtin_fma(col[(size_t)k * ldt], a[kc + k], s);
+    partial[(size_t)blockIdx.x * PRED_RB + r] = s;
+}
+
+__global__ __launch_bounds__(256) void bt_finish_kernel(const double* __restrict__ A, int ld, int Np, int N, int ib, int nchunks,
+                                                        const double* __restrict__ partial, const double* __restrict__ DT2,
+                                                        double* __restrict__ a) {
+    __shared__ double rv[PRED_RB];
+    const int r = threadIdx.x, i = ib * PRED_RB + r;
+    double v = (i < N) ? A[(size_t)i * ld + Np] : 0.0;      // z_i sits in row Np of the factor array
+    for (int c = 0; c < nchunks; ++c) v -= partial[(size_t)c * PRED_RB + r];
+    rv[r] = v;
+    __syncthreads();
+    const double* D = DT2 + (size_t)ib * PRED_RB * PRED_RB;
+    double s = 0.0;
+#pragma unroll 16
+    for (int k = 0; k < PRED_RB; ++k) s = __builtin_fma(D[r + (size_t)k * PRED_RB], rv[k], s);   // upper triangular: zeros below the diagonal
+    a[i] = s;
+}
+
+// W = L⁻ᵀ V in place on every slab: for the row steps from the last to the first,
+//     R_i = V_i − Σ_{j>i} Lᵀ_ij W_j        (GemmDirect: A = rows of LT, B = this slab's finished rows)
+//     W_i = Dinv2_iᵀ R_i                    (R in LDS; DT2 holds the transposed 256×256 inverses: upper
+//                                            triangular, a row only needs the k ≥ its own 64-row slice)
+template <class G>
+__global__ __launch_bounds__(G::NTHREADS) void backsolve_kernel(const double* __restrict__ LT, int ldt, int Np,
+                                                                const double* __restrict__ DT2,
+                                                                double* __restrict__ Vscratch) {
+    static_assert(G::WC == 1 && G::BM == 2 * BLK, "written for 256-row steps");
+    constexpr int RB = G::BM, BN = G::BN, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
+    extern __shared__ double lds[];
+    double* Rs = lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave, wc = 0;
+    double* V = Vscratch + (size_t)blockIdx.x * Np * BN;
+    const int nb = Np / RB;
+    for (int ib = nb - 1; ib >= 0; --ib) {
+        v4d acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        const int k0 = (ib + 1) * RB;
+        G::template run<1>(LT + (size_t)ib * RB + (size_t)k0 * ldt, ldt, V + (size_t)k0 * BN, BN, Np - k0, acc);
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int row = G::row_of(wr, m, lane);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = G::col_of(wc, n, i, lane);
+                    Rs[row * LDR + col] = V[(size_t)(ib * RB + row) * BN + col] - acc[m][n][i];
+                }
+        }
+        __syncthreads();                                   // R tile complete
+        v4d acc2[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        const int kk0 = (TM * 16) * wr;                    // upper triangular: rows of wave w need k >= 64 w
+        G::run_Blds(DT2 + (size_t)ib * RB * RB + (size_t)kk0 * RB, RB, Rs + (size_t)kk0 * LDR, LDR, RB - kk0, acc2);
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int row = ib * RB + G::row_of(wr, m, lane);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) V[(size_t)row * BN + G::col_of(wc, n, i, lane)] = acc2[m][n][i];
+        }
+        __syncthreads();                                   // W_ib visible to the workgroup; Rs reusable
+    }
+}
+
+// ∇μ, ∇σ² from the W slabs:  with q_i = α² h(r_i),
+//     ∇μ_m  = ∇m_m + (u*_m Σ_i a_i q_i − Σ_i a_i q_i u_i,m) / λ_m ,   ∇σ²_m = −2 (u*_m Σ_i w_i q_i − Σ_i w_i q_i u_i,m) / λ_m
+// (u = x ⊘ λ).  One workgroup per 32-candidate slab: lanes run along the candidates, 8 row subsets;
+// the rows' coordinates and a_i are staged through LDS 64 rows at a time (broadcast reads), the W
+// loads of a chunk are issued together.  Dimensions are handled 16 at a time (registers).
+constexpr int GRAD_MAX_D = 16;
+constexpr int GRAD_CHUNK = 64;
+__global__ __launch_bounds__(256) void grad_accum_kernel(const double* __restrict__ Wslabs, const double* __restrict__ avec,
+                                                         int Np, int N, const double* __restrict__ Xsc,
+                                                         const double* __restrict__ Csc, int d, int Mp, int M, int kern,
+                                                         double amp2, const double* __restrict__ invlam,
+                                                         const unsigned char* __restrict__ discrete,
+                                                         const double* __restrict__ mean_grad,
+                                                         double* __restrict__ dmu, double* __restrict__ dvar) {
+    constexpr int BN = 32;
+    extern __shared__ double glds[];
+    double* xs = glds;                                       // [d][GRAD_CHUNK] scaled coordinates of the chunk's rows
+    double* as = xs + (size_t)d * GRAD_CHUNK;                // [GRAD_CHUNK]     a_i
+    double* red = as + GRAD_CHUNK;                           // [8][2(GRAD_MAX_D+1)][BN]
+    const int tid = threadIdx.x, c = tid & 31, rs = tid >> 5;
+    const int j = blockIdx.x * BN + c;
+    const double* W = Wslabs + (size_t)blockIdx.x * Np * BN;
+    for (int m0 = 0; m0 < d; m0 += GRAD_MAX_D) {            // d > 16: passes of 16 dimensions
+        const int dm = (d - m0 < GRAD_MAX_D) ? (d - m0) : GRAD_MAX_D;
+        double S1 = 0.0, S2 = 0.0, T1[GRAD_MAX_D], T2[GRAD_MAX_D];
+#pragma unroll
+        for (int m = 0; m < GRAD_MAX_D; ++m) T1[m] = T2[m] = 0.0;
+        for (int r0 = 0; r0 < N; r0 += GRAD_CHUNK) {
+            __syncthreads();
+            for (int idx = tid; idx < d * GRAD_CHUNK; idx += 256) {
+                const int m = idx / GRAD_CHUNK, rr = idx - m * GRAD_CHUNK;
+                xs[idx] = Xsc[(size_t)m * Np + r0 + rr];     // rows beyond N are padding inside Np: harmless, masked below
+            }
+            if (tid < GRAD_CHUNK) as[tid] = avec[r0 + tid];
+            double w[GRAD_CHUNK / 8];
+#pragma unroll
+            for (int k = 0; k < GRAD_CHUNK / 8; ++k) w[k] = W[(size_t)(r0 + rs + 8 * k) * BN + c];
+            __syncthreads();
+#pragma unroll 2
+            for (int k = 0; k < GRAD_CHUNK / 8; ++k) {
+                const int rr = rs + 8 * k;
+                if (r0 + rr >= N) break;
+                double r2 = 0.0;
+                for (int m = 0; m < d; ++m) {
+                    const double diff = Csc[(size_t)m * Mp + j] - xs[m * GRAD_CHUNK + rr];
+                    r2 = __builtin_fma(diff, diff, r2);
+                }
+                const double q = amp2 * kappa_prime_over_r_r2(kern, r2);
+                const double qa = q * as[rr], qw = q * w[k];
+                S1 += qa;
+                S2 += qw;
+#pragma unroll
+                for (int m = 0; m < GRAD_MAX_D; ++m)
+                    if (m < dm) {
+                        const double x = xs[(m0 + m) * GRAD_CHUNK + rr];
+                        T1[m] = __builtin_fma(qa, x, T1[m]);
+                        T2[m] = __builtin_fma(qw, x, T2[m]);
+                    }
+            }
+        }
+        __syncthreads();
+        double* rd = red + (size_t)rs * (2 * (GRAD_MAX_D + 1)) * BN;
+        rd[0 * BN + c] = S1;
+        rd[1 * BN + c] = S2;
+#pragma unroll
+        for (int m = 0; m < GRAD_MAX_D; ++m) {
+            rd[(2 + 2 * m) * BN + c] = T1[m];
+            rd[(3 + 2 * m) * BN + c] = T2[m];
+        }
+        __syncthreads();
+        if (rs == 0 && j < M) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < 8; ++k) {
+                const double* rk = red + (size_t)k * (2 * (GRAD_MAX_D + 1)) * BN;
+                s1 += rk[c];
+                s2 += rk[BN + c];
+            }
+            for (int m = 0; m < dm; ++m) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int k = 0; k < 8; ++k) {
+                    const double* rk = red + (size_t)k * (2 * (GRAD_MAX_D + 1)) * BN;
+                    t1 += rk[(2 + 2 * m) * BN + c];
+                    t2 += rk[(3 + 2 * m) * BN + c];
+                }
+                const int mm = m0 + m;
+                const double u = Csc[(size_t)mm * Mp + j], il = invlam[mm];
+                const bool disc = discrete && discrete[mm];
+                const double g1 = disc ? 0.0 : (u * s1 - t1) * il;
+                const double g2 = disc ? 0.0 : -2.0 * (u * s2 - t2) * il;
+                dmu[(size_t)j * d + mm] = g1 + (mean_grad ? mean_grad[(size_t)j * d + mm] : 0.0);
+                dvar[(size_t)j * d + mm] = g2;
+            }
+        }
+    }
+}
+
 // a5: full posterior covariance  Σ = K** − VᵀV + 1e-18·I  (mean_and_cov, gaussian_process.jl:180-184;
 // AbstractGPs cov(post(X*))) from the V slabs the prediction kernel left in its scratch
 // (V(n, j) = Vs[(j/BN * Np + n) * BN + j % BN]).  16×16 outputs per workgroup, n staged through LDS.
@@ -461,6 +667,104 @@ __global__ __launch_bounds__(ACQ_EPI_THREADS) void acq_epilogue_kernel(const dou
     if (threadIdx.x == 0) {
         res[0] = sv[0];
         reinterpret_cast<long*>(res)[1] = si[0];
+    }
+}
+
+// Acquisition value and gradient w.r.t. the candidate for one hyper-parameter sample, from the P
+// outputs' moments and moment gradients (mu/var: [p][M]; dmu/dvar: [p][j*d + m]) — the chain rule
+// through construct_ei (expected_improvement.jl:68-101,113-114):
+//   μf = cᵀμ, σf = sqrt(c²ᵀσ²), z = (μf − b)/σf :  ∇EI = Φ(z) ∇μf + φ(z) ∇σf ,  ∇σf = c²ᵀ∇σ² / (2σf)
+//   FP = Π_p Φ(t_p), t_p = (ymax_p − μ_p)/s_p, s_p = sqrt(σ²_p):
+//        ∇FP = Σ_p (Π_{q≠p} Φ(t_q)) φ(t_p) ∇t_p ,  ∇t_p = −∇μ_p/s_p − (ymax_p − μ_p) ∇σ²_p / (2 s_p³)
+//   acq = EI·FP (or EI, or FP, or 0 by mode); outside the domain mask: acq = 0, ∇acq = 0 (make_safe).
+// Variances clipped to 0 (or exactly 0) contribute no σ-gradient.
+__global__ void ei_grad_kernel(const double* __restrict__ mu, const double* __restrict__ var, const double* __restrict__ dmu,
+                               const double* __restrict__ dvar, int M, int d, EiPar par,
+                               const double* __restrict__ coefs_dev, const double* __restrict__ ymax_dev,
+                               const unsigned char* __restrict__ mask, double* __restrict__ acq,
+                               double* __restrict__ dacq) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const int P = par.P, mode = par.mode;
+    const size_t dm = (size_t)d * M;
+    double* gout = dacq + (size_t)j * d;
+    if (mode == 0 || (mask && !mask[j])) {
+        acq[j] = 0.0;
+        for (int m = 0; m < d; ++m) gout[m] = 0.0;
+        return;
+    }
+    // pass 1: scalars
+    double muf = 0.0, vf = 0.0, fp = 1.0;
+    bool poison = false;
+    for (int p = 0; p < P; ++p) {
+        const double cf = (P <= EI_MAXP) ? par.coefs[p] : coefs_dev[p];
+        const double ym = (mode & 2) ? ((P <= EI_MAXP) ? par.ymax[p] : ymax_dev[p]) : INFINITY;
+        double m_ = mu[(size_t)p * M + j], v = var[(size_t)p * M + j];
+        if (v < 0.0) {
+            if (v >= -MAX_NEG_VAR) v = 0.0;
+            else poison = true;
+        }
+        muf = __builtin_fma(cf, m_, muf);
+        vf = __builtin_fma(cf * cf, v, vf);
+        if ((mode & 2) && !(isinf(ym) && ym > 0.0)) {
+            const double sd = sqrt(v);
+            const double t = (sd == 0.0 && ym == m_) ? INFINITY : (ym - m_) / sd;
+            fp *= normcdf_dev(t);
+        }
+    }
+    double ei = 0.0, Phi = 0.0, phi_over_2sf = 0.0;
+    if (mode & 1) {
+        const double sf = sqrt(vf), diff = muf - par.best;
+        if (diff == 0.0 && sf == 0.0) ei = 0.0;
+        else {
+            const double z = diff / sf;
+            Phi = normcdf_dev(z);
+            const double ph = normpdf_dev(z);
+            ei = diff * Phi + sf * ph;
+            phi_over_2sf = (sf > 0.0) ? ph / (2.0 * sf) : 0.0;
+        }
+    }
+    double a;
+    if (mode & 1) a = (mode & 2) ? ei * fp : ei;
+    else a = fp;
+    acq[j] = poison ? -INFINITY : a;
+    // pass 2: gradient, one coordinate at a time
+    for (int m = 0; m < d; ++m) {
+        double dmuf = 0.0, dvf = 0.0, dfp = 0.0;
+        for (int p = 0; p < P; ++p) {
+            const double cf = (P <= EI_MAXP) ? par.coefs[p] : coefs_dev[p];
+            const double gm = dmu[(size_t)p * dm + (size_t)j * d + m];
+            double v = var[(size_t)p * M + j];
+            const bool clipped = !(v > 0.0);
+            const double gv = clipped ? 0.0 : dvar[(size_t)p * dm + (size_t)j * d + m];
+            dmuf = __builtin_fma(cf, gm, dmuf);
+            dvf = __builtin_fma(cf * cf, gv, dvf);
+            if (mode & 2) {
+                const double ym = (P <= EI_MAXP) ? par.ymax[p] : ymax_dev[p];
+                if (!(isinf(ym) && ym > 0.0) && !clipped) {
+                    const double m_ = mu[(size_t)p * M + j], sd = sqrt(v);
+                    const double t = (ym - m_) / sd;
+                    const double dt = -gm / sd - (ym - m_) * gv / (2.0 * sd * v);
+                    double others = 1.0;
+                    for (int q = 0; q < P; ++q) {
+                        if (q == p) continue;
+                        const double yq = (P <= EI_MAXP) ? par.ymax[q] : ymax_dev[q];
+                        if (isinf(yq) && yq > 0.0) continue;
+                        double vq = var[(size_t)q * M + j];
+                        if (vq < 0.0) vq = 0.0;
+                        const double mq = mu[(size_t)q * M + j], sq = sqrt(vq);
+                        const double tq = (sq == 0.0 && yq == mq) ? INFINITY : (yq - mq) / sq;
+                        others *= normcdf_dev(tq);
+                    }
+                    dfp = __builtin_fma(others * normpdf_dev(t), dt, dfp);
+                }
+            }
+        }
+        const double dei = Phi * dmuf + phi_over_2sf * dvf;
+        double gA;
+        if (mode & 1) gA = (mode & 2) ? dei * fp + ei * dfp : dei;
+        else gA = dfp;
+        gout[m] = poison ? 0.0 : gA;
     }
 }
 

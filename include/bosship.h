@@ -126,6 +126,20 @@ int boss_gp_loglike_batch(int device, int kernel, int d, int N, const double* X,
 int boss_gp_predict(boss_gp_t* gp, int M, const double* Xs, const double* mean_Xs,
                     double* mu, double* var, long* bad_index);
 
+/* Posterior moments AND their analytic gradients w.r.t. the candidate coordinates.
+ * Replaces: the derivative of mean_and_var(post, x) that the reference obtains by pushing
+ * ForwardDiff duals through AbstractGPs when OptimizationAM refines candidates
+ * (src/acquisition_maximizers/optimization.jl:36 AutoForwardDiff, :89-118; acquisition closure
+ * src/acquisitions/expected_improvement.jl:74-84):
+ *   dmu[:,j]  = grad m(x*_j) + sum_i a_i grad k(x_i, x*_j),   a = (K+sigma^2 I)^-1 (y - m)
+ *   dvar[:,j] = -2 sum_i w_ij grad k(x_i, x*_j),              w_j = (K+sigma^2 I)^-1 k*_j
+ *   Xs d×M; mean_Xs M or NULL; mean_grad d×M (gradient of the prior mean at the candidates) or NULL;
+ *   mu, var M each (var through _clip_var, as boss_gp_predict); dmu, dvar d×M column-major.
+ * Dimensions flagged discrete are rounded inside the kernel (DiscreteKernel), their gradient is 0.
+ * Costs about two boss_gp_predict passes (forward substitution + its adjoint). */
+int boss_gp_predict_grad(boss_gp_t* gp, int M, const double* Xs, const double* mean_Xs, const double* mean_grad,
+                         double* mu, double* var, double* dmu, double* dvar, long* bad_index);
+
 /* Replaces: mean_and_cov(post, X::Matrix) / cov (gaussian_process.jl:163-167,180-184):
  *   Sigma = K** - V'V + 1e-18 I (M×M, column-major, full symmetric), diagonal through _clip_var.
  * Not on the acquisition path (EI only needs the diagonal); provided so the whole posterior API
@@ -169,6 +183,19 @@ int boss_acq_ei_moments(int device, int P, int S, int M, const double* mu, const
                         const double* fit_coefs, const double* y_max, int has_best, double best,
                         const unsigned char* valid_mask, double* acq_out, long* argmax_out,
                         double* max_out);
+
+/* Acquisition value AND its gradient w.r.t. the candidates, for one hyper-parameter
+ * sample (MAP).  Replaces: differentiating construct_acquisition(::ExpectedImprovement)
+ * (src/acquisitions/expected_improvement.jl:49-101,113-114) with ForwardDiff inside OptimizationAM's
+ * multistart refinement (src/acquisition_maximizers/optimization.jl:36,89-118):
+ *   gps        P handles (one per output), all on one device;
+ *   Xs         d×M candidates (host);  mean_Xs NULL or [p][M];  mean_grad NULL or [p][d×M];
+ *   fit_coefs, y_max, has_best/best, valid_mask: as boss_acq_ei;
+ *   acq_out    M values;  dacq_out d×M column-major (gradient of acq_out[j] w.r.t. candidate j).
+ * The EI x feasibility chain rule runs on the device behind boss_gp_predict_grad's moment gradients. */
+int boss_acq_ei_grad(int P, boss_gp_t* const* gps, int M, const double* Xs, const double* mean_Xs,
+                     const double* mean_grad, const double* fit_coefs, const double* y_max, int has_best,
+                     double best, const unsigned char* valid_mask, double* acq_out, double* dacq_out);
 
 /* ---- measurement helpers (bench.py / profiles) ------------------------------------------ */
 /* issue-rate microbenchmark of v_mfma_f64_16x16x4_f64: every SIMD of the device issues

@@ -274,6 +274,82 @@ def gp_mean_and_cov(post: GPPosterior, Xs, mean_s=None):
     return mu, S
 
 
+def kappa_prime_over_r(kernel: int, r: np.ndarray) -> np.ndarray:
+    """h(r) = κ'(r)/r of the radial profiles above (finite at r = 0):
+    Matern32 -3 e^{-√3 r};  Matern52 -(5/3)(1+√5 r) e^{-√5 r};  SqExp -e^{-r²/2}.
+    What ForwardDiff computes through KernelFunctions when the reference differentiates the
+    acquisition (src/acquisition_maximizers/optimization.jl:36 AutoForwardDiff, :89-118)."""
+    if kernel == MATERN32:
+        return -3.0 * np.exp(-_SQRT3 * r)
+    if kernel == MATERN52:
+        s = _SQRT5 * r
+        return -(5.0 / 3.0) * (1.0 + s) * np.exp(-s)
+    if kernel == SQEXP:
+        return -np.exp(-0.5 * r * r)
+    raise ValueError(f"unknown kernel id {kernel}")
+
+
+def gp_mean_and_var_grad(post: GPPosterior, Xs, mean_s=None, mean_grad_s=None):
+    """Posterior mean / (unclipped) variance at the columns of Xs AND their gradients w.r.t. the
+    candidate coordinates — the derivative of `mean_and_var(post, x)` (gaussian_process.jl:169-173):
+        ∇μ(x*)  = ∇m(x*) + Σ_i a_i ∇k(x_i, x*) ,         a = (K+σ²I)⁻¹ (y − m)
+        ∇σ²(x*) = −2 Σ_i w_i ∇k(x_i, x*) ,                w = (K+σ²I)⁻¹ k*      (k(x*,x*) is constant)
+        ∇k(x_i, x*)_m = α² h(r_i) (x*_m − x_i,m) / λ_m²
+    Dimensions flagged discrete are rounded inside the kernel (DiscreteKernel), so their gradient is 0.
+    Returns mu[M], var[M] (with the 1e-18 jitter, not clipped), dmu[d,M], dvar[d,M]."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    if Xs.ndim == 1:
+        Xs = Xs[:, None]
+    h = post.h
+    Xa = discrete_round(post.X, h.discrete)
+    Xb = discrete_round(Xs, h.discrete)
+    r = scaled_distance(Xa, Xb, h.lengthscale)                       # N×M
+    amp2 = h.amplitude ** 2
+    Ks = amp2 * kappa(h.kernel, r)
+    Q = amp2 * kappa_prime_over_r(h.kernel, r)                       # N×M
+    V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
+    W = sla.solve_triangular(post.L, V, lower=True, trans="T", check_finite=False)    # (K+σ²I)⁻¹ k*
+    m = np.zeros(Xs.shape[1]) if mean_s is None else np.asarray(mean_s, dtype=np.float64)
+    mu = m + Ks.T @ post.a
+    var = amp2 * kappa(h.kernel, np.zeros(Xs.shape[1])) - np.sum(V * V, axis=0) + PREDICT_JITTER
+    lam2 = h.lengthscale ** 2
+    d = Xs.shape[0]
+    dmu = np.zeros((d, Xs.shape[1]))
+    dvar = np.zeros((d, Xs.shape[1]))
+    QA = Q * post.a[:, None]
+    QW = Q * W
+    for k in range(d):
+        diff = Xb[k][None, :] - Xa[k][:, None]                       # x*_k − x_i,k   (N×M)
+        dmu[k] = np.sum(QA * diff, axis=0) / lam2[k]
+        dvar[k] = -2.0 * np.sum(QW * diff, axis=0) / lam2[k]
+    if h.discrete is not None:
+        dmu[h.discrete] = 0.0
+        dvar[h.discrete] = 0.0
+    if mean_grad_s is not None:
+        dmu = dmu + np.asarray(mean_grad_s, dtype=np.float64)
+    return mu, var, dmu, dvar
+
+
+def expected_improvement_lin_grad(fit_coefs, mu, var, dmu, dvar, best_yet: float):
+    """EI(LinFitness) (expected_improvement.jl:93-101) and its gradient w.r.t. the candidate, by the
+    chain rule through μf = cᵀμ, σf = sqrt(c²ᵀσ²):  ∂EI/∂μf = Φ(z), ∂EI/∂σf = φ(z), z = (μf − b)/σf.
+    mu, var: P×M;  dmu, dvar: P×d×M.  Returns (ei[M], dei[d,M]); where σf = 0 the σ-term is dropped."""
+    c = np.asarray(fit_coefs, dtype=np.float64)
+    mu, var = np.atleast_2d(mu), np.atleast_2d(var)
+    muf = c @ mu
+    vf = (c * c) @ var
+    sf = np.sqrt(vf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = (muf - best_yet) / sf
+    ei = expected_improvement_lin(fit_coefs, mu, var, best_yet)
+    dmuf = np.einsum("p,pdm->dm", c, dmu)
+    dvf = np.einsum("p,pdm->dm", c * c, dvar)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dsf = np.where(sf > 0, dvf / (2.0 * sf), 0.0)
+    dei = normcdf(z) * dmuf + normpdf(z) * dsf
+    return ei, dei
+
+
 def model_mean_and_var(posts: Sequence[GPPosterior], Xs, means_s=None):
     """DefaultModelPosterior fan-out over outputs (src/posterior.jl:67-72): rows = outputs -> P×M."""
     mus, vars_ = [], []
@@ -413,6 +489,68 @@ def ei_acquisition(posts_or_samples, Xs, fit_coefs, y_max, best_yet, valid_mask=
     if valid_mask is not None:
         acq = np.where(np.asarray(valid_mask, dtype=bool), acq, 0.0)    # :58-65
     return acq
+
+
+def feas_prob_grad(mu, var, dmu, dvar, y_max):
+    """feas_prob (expected_improvement.jl:113-114) and its gradient w.r.t. the candidate:
+    FP = Π_p Φ(t_p), t_p = (ymax_p − μ_p)/sqrt(σ²_p); outputs with ymax = +Inf are skipped (factor 1).
+    mu, var: P×M; dmu, dvar: P×d×M.  Returns (fp[M], dfp[d,M])."""
+    mu, var = np.atleast_2d(mu), np.atleast_2d(var)
+    P, M = mu.shape
+    d = dmu.shape[1]
+    y_max = np.asarray(y_max, dtype=np.float64)
+    Phi = np.ones((P, M))
+    fac = np.zeros((P, d, M))
+    for p in range(P):
+        if np.isposinf(y_max[p]):
+            continue
+        v = np.maximum(var[p], 0.0)
+        s = np.sqrt(v)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where((s == 0) & (y_max[p] == mu[p]), np.inf, (y_max[p] - mu[p]) / s)
+            dt = np.where(v > 0, -dmu[p] / s - (y_max[p] - mu[p]) * dvar[p] / (2.0 * s * v), 0.0)
+        Phi[p] = normcdf(t)
+        fac[p] = np.where(v > 0, normpdf(t), 0.0) * dt
+    fp = np.prod(Phi, axis=0)
+    dfp = np.zeros((d, M))
+    for p in range(P):
+        others = np.prod(np.delete(Phi, p, axis=0), axis=0) if P > 1 else np.ones(M)
+        dfp += others * fac[p]
+    return fp, dfp
+
+
+def ei_acquisition_grad(posts: Sequence[GPPosterior], Xs, fit_coefs, y_max, best_yet, valid_mask=None,
+                        means_s=None, mean_grads_s=None):
+    """construct_ei for ONE posterior sample (expected_improvement.jl:68-84) wrapped by make_safe (:58-65),
+    with its gradient w.r.t. the candidates (what ForwardDiff yields inside OptimizationAM).
+    Returns (acq[M], dacq[d,M])."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    d, M = Xs.shape
+    P = len(posts)
+    mu, var = np.zeros((P, M)), np.zeros((P, M))
+    dmu, dvar = np.zeros((P, d, M)), np.zeros((P, d, M))
+    for p, post in enumerate(posts):
+        ms = None if means_s is None else means_s[p]
+        mg = None if mean_grads_s is None else mean_grads_s[p]
+        mu[p], v, dmu[p], dvar[p] = gp_mean_and_var_grad(post, Xs, ms, mg)
+        var[p] = clip_var(v)
+        dvar[p] = np.where(var[p] > 0, dvar[p], 0.0)
+    constrained = y_max is not None
+    if (not constrained) and best_yet is None:
+        acq, dacq = np.zeros(M), np.zeros((d, M))
+    elif best_yet is None:
+        acq, dacq = feas_prob_grad(mu, var, dmu, dvar, y_max)
+    elif not constrained:
+        acq, dacq = expected_improvement_lin_grad(fit_coefs, mu, var, dmu, dvar, best_yet)
+    else:
+        ei, dei = expected_improvement_lin_grad(fit_coefs, mu, var, dmu, dvar, best_yet)
+        fp, dfp = feas_prob_grad(mu, var, dmu, dvar, y_max)
+        acq, dacq = ei * fp, dei * fp + ei * dfp
+    if valid_mask is not None:
+        vm = np.asarray(valid_mask, dtype=bool)
+        acq = np.where(vm, acq, 0.0)
+        dacq = np.where(vm[None, :], dacq, 0.0)
+    return acq, dacq
 
 
 def argmax_first(vals):

@@ -120,6 +120,27 @@ def batch_cfg(S=512, N=1024, d=8):
     print(f"loglike_batch S={S} N={N}: first {t1*1e3:.1f} ms, steady {dt*1e3:.1f} ms  ({S/dt:.0f} factorizations/s, {fl/dt/1e12:.2f} TF)  rel err {err:.1e} ok={int((st==0).sum())}", flush=True)
 
 
+def grad_timing(d=8, N=4096, M=8192):
+    """Posterior moments + analytic gradients for 8192 candidates (forward + adjoint substitution)."""
+    X, y, Xs = problem(d, N, M)
+    lam = np.full(d, 0.5)
+    g = api.GP(X, y, "matern52")
+    g.update(lam, 1.0, 0.05)
+    g.predict_grad(Xs)
+    t = time.time()
+    for _ in range(3):
+        mu, var, dmu, dvar = g.predict_grad(Xs)
+    dt = (time.time() - t) / 3
+    t = time.time()
+    for _ in range(3):
+        g.predict(Xs)
+    dp = (time.time() - t) / 3
+    post = O.gp_fit(X, y, "matern52", lam, 1.0, 0.05)
+    mu_o, var_o, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs[:, :64])
+    print(f"predict_grad N={N} M={M}: {dt*1e3:.2f} ms ({M/dt/1e6:.2f} M gradient evals/s) vs predict {dp*1e3:.2f} ms;  "
+          f"|d dmu|={np.abs(dmu[:, :64]-dmu_o).max():.1e} |d dvar|={np.abs(dvar[:, :64]-dvar_o).max():.1e}", flush=True)
+
+
 def batch_big(N=4096, d=8):
     """Batched posterior updates at the BASELINE size: S hyper-parameter sets on the same data."""
     X, y, _ = problem(d, N, 1)
@@ -186,6 +207,8 @@ if __name__ == "__main__":
         append_timing()
     if "batch" in stages:
         batch_cfg()
+    if "grad" in stages:
+        grad_timing()
     if "batch_big" in stages:
         batch_big()
     if "multi" in stages:

@@ -621,6 +621,102 @@ def test_two_host_threads_share_a_device(api, O):
     assert not errs, errs[0]
 
 
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+@pytest.mark.parametrize("d,N,M", [(1, 5, 3), (3, 130, 45), (8, 700, 100), (17, 300, 33)])
+def test_posterior_gradients(api, O, kernel, d, N, M):
+    """boss_gp_predict_grad: mean / variance and their gradients w.r.t. the candidates
+    against the oracle's analytic restatement (itself pinned to finite differences on the CPU)."""
+    rng = np.random.default_rng(31 * d + N)
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0) / np.sqrt(d) + 0.05 * rng.standard_normal(N)
+    mean = 0.2 + 0.3 * X[0]
+    Xs = rng.uniform(0, 1, (d, M))
+    ms = 0.2 + 0.3 * Xs[0]
+    mg = np.zeros((d, M))
+    mg[0] = 0.3
+    lam = rng.uniform(0.4, 0.9, d) * np.sqrt(d)
+    g = api.GP(X, y, kernel)
+    g.update(lam, 1.2, 0.05, mean)
+    post = O.gp_fit(X, y, kernel, lam, 1.2, 0.05, mean=mean)
+    mu, var, dmu, dvar = g.predict_grad(Xs, ms, mg)
+    mu_o, var_o, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs, ms, mg)
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, O.clip_var(var_o), rtol=0, atol=1e-9)
+    scale = 1.0 + np.abs(dmu_o).max()
+    assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8 * scale), np.abs(dmu - dmu_o).max()
+    assert np.allclose(dvar, dvar_o, rtol=0, atol=1e-8 * (1.0 + np.abs(dvar_o).max())), np.abs(dvar - dvar_o).max()
+    # the plain prediction still works afterwards (the backward pass ran in place on the scratch slabs)
+    mu2, var2 = g.predict(Xs, ms)
+    assert np.allclose(mu2, mu, rtol=0, atol=1e-12) and np.allclose(var2, var, rtol=0, atol=1e-12)
+    # a second call reuses the transposed factor; after an update it is rebuilt
+    g.update(lam * 1.1, 1.0, 0.06, mean)
+    post2 = O.gp_fit(X, y, kernel, lam * 1.1, 1.0, 0.06, mean=mean)
+    _, _, dmu2, dvar2 = g.predict_grad(Xs, ms, mg)
+    _, _, dmu2_o, dvar2_o = O.gp_mean_and_var_grad(post2, Xs, ms, mg)
+    assert np.allclose(dmu2, dmu2_o, rtol=0, atol=1e-8 * (1.0 + np.abs(dmu2_o).max()))
+    assert np.allclose(dvar2, dvar2_o, rtol=0, atol=1e-8 * (1.0 + np.abs(dvar2_o).max()))
+    g.close()
+
+
+def test_posterior_gradients_discrete_and_ei_chain(api, O):
+    rng = np.random.default_rng(8)
+    d, N, M = 3, 200, 50
+    X = rng.uniform(0, 5, (d, N))
+    y = np.cos(X).sum(0)
+    disc = [True, False, False]
+    lam = np.array([1.5, 2.0, 1.0])
+    g = api.GP(X, y, "matern52", disc)
+    g.update(lam, 1.0, 0.1)
+    post = O.gp_fit(X, y, "matern52", lam, 1.0, 0.1, discrete=disc)
+    Xs = rng.uniform(0, 5, (d, M))
+    mu, var, dmu, dvar = g.predict_grad(Xs)
+    mu_o, var_o, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs)
+    assert np.all(dmu[0] == 0) and np.all(dvar[0] == 0)
+    assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8) and np.allclose(dvar, dvar_o, rtol=0, atol=1e-8)
+    # gradient of EI by the chain rule from the device moments == oracle
+    b = float(y.max()) - 0.5
+    ei, dei = O.expected_improvement_lin_grad([1.0], mu[None], var[None], dmu[None], dvar[None], b)
+    ei_o, dei_o = O.expected_improvement_lin_grad([1.0], mu_o[None], var_o[None], dmu_o[None], dvar_o[None], b)
+    assert np.allclose(ei, ei_o, rtol=0, atol=1e-10) and np.allclose(dei, dei_o, rtol=0, atol=1e-8)
+    g.close()
+
+
+@pytest.mark.parametrize("mode", ["both", "best_only", "cons_only", "none"])
+def test_acquisition_gradient(api, O, mode):
+    """boss_acq_ei_grad: EI × feasibility and its gradient w.r.t. the candidates, two outputs with prior
+    means, all four construct_ei variants, make_safe mask."""
+    rng = np.random.default_rng(77)
+    d, N, M, P = 3, 260, 70, 2
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), X[0] - X[1] + 0.2 * np.cos(4 * X[2])])
+    lam = [np.array([0.4, 0.6, 0.5]), np.array([0.5, 0.5, 0.7])]
+    mean_f = [lambda Z: 0.1 + 0.2 * Z[0], lambda Z: -0.1 * Z[1]]
+    mean_g = [np.array([0.2, 0.0, 0.0]), np.array([0.0, -0.1, 0.0])]
+    gps, posts = [], []
+    for p in range(P):
+        g = api.GP(X, Y[p], "matern52")
+        g.update(lam[p], 1.0 + 0.2 * p, 0.05, mean_f[p](X))
+        gps.append(g)
+        posts.append(O.gp_fit(X, Y[p], "matern52", lam[p], 1.0 + 0.2 * p, 0.05, mean=mean_f[p](X)))
+    Xs = np.asfortranarray(rng.uniform(-0.05, 1.05, (d, M)))
+    y_max = [np.inf, 0.3] if mode in ("both", "cons_only") else None
+    coefs = [1.0, 0.2]
+    b = O.best_so_far(coefs, Y, [np.inf, 0.3]) if mode in ("both", "best_only") else None
+    mask = O.in_bounds(Xs, np.zeros(d), np.ones(d))
+    ms = [mean_f[p](Xs) for p in range(P)]
+    mgs = [np.repeat(mean_g[p][:, None], M, axis=1) for p in range(P)]
+    acq, dacq = api.acq_ei_grad(gps, Xs, coefs, y_max, b, mask, ms, mgs)
+    acq_o, dacq_o = O.ei_acquisition_grad(posts, Xs, coefs, y_max, b, valid_mask=mask, means_s=ms, mean_grads_s=mgs)
+    assert np.allclose(acq, acq_o, rtol=0, atol=1e-11), np.abs(acq - acq_o).max()
+    assert np.allclose(dacq, dacq_o, rtol=0, atol=1e-9 * (1.0 + np.abs(dacq_o).max())), np.abs(dacq - dacq_o).max()
+    assert np.all(dacq[:, ~mask] == 0.0) and np.all(acq[~mask] == 0.0)
+    # the value agrees with the non-gradient entry point
+    cand = api.Candidates(Xs)
+    acq2, _, _ = api.acq_ei([gps], cand, coefs, y_max, b, mask, np.stack(ms)[None])
+    assert np.allclose(acq, acq2, rtol=0, atol=1e-13)
+    for g in gps:
+        g.close()
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch

@@ -81,3 +81,69 @@ def test_non_pd_reports_posdef_and_neg_inf():
     with pytest.raises(O.PosDefException):
         O.gp_fit(X, y, "sqexp", [1.], 1.0, 0.0)
     assert O.gp_data_loglike_slice(X, y, "sqexp", [1.], 1.0, 0.0) == -np.inf
+
+
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+def test_gradient_restatement_against_finite_differences(kernel):
+    """gp_mean_and_var_grad / expected_improvement_lin_grad (the analytic derivatives the device path
+    of SURVEY §8f3 must reproduce) against central finite differences of the oracle itself."""
+    rng = np.random.default_rng(5)
+    d, N, M = 3, 40, 7
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0) + 0.05 * rng.standard_normal(N)
+    lam = np.array([0.4, 0.7, 0.5])
+    post = O.gp_fit(X, y, kernel, lam, 1.3, 0.05, mean=np.full(N, 0.2))
+    Xs = rng.uniform(0.05, 0.95, (d, M))
+    ms = np.full(M, 0.2)
+    mu, var, dmu, dvar = O.gp_mean_and_var_grad(post, Xs, ms)
+    mu0, var0 = O.gp_mean_and_var(post, Xs, ms, clip=False)
+    assert np.allclose(mu, mu0, rtol=0, atol=1e-13) and np.allclose(var, var0, rtol=0, atol=1e-13)
+    eps = 1e-6
+    b = float(y.max()) - 0.3
+    ei, dei = O.expected_improvement_lin_grad([1.0], mu[None], var[None], dmu[None], dvar[None], b)
+    for k in range(d):
+        Xp, Xm = Xs.copy(), Xs.copy()
+        Xp[k] += eps
+        Xm[k] -= eps
+        mp, vp = O.gp_mean_and_var(post, Xp, ms, clip=False)
+        mm, vm = O.gp_mean_and_var(post, Xm, ms, clip=False)
+        assert np.allclose(dmu[k], (mp - mm) / (2 * eps), rtol=1e-6, atol=1e-7)
+        assert np.allclose(dvar[k], (vp - vm) / (2 * eps), rtol=1e-6, atol=1e-7)
+        eip = O.expected_improvement_lin([1.0], mp[None], vp[None], b)
+        eim = O.expected_improvement_lin([1.0], mm[None], vm[None], b)
+        assert np.allclose(dei[k], (eip - eim) / (2 * eps), rtol=1e-5, atol=1e-8)
+    # discrete dimensions: rounded inside the kernel -> zero gradient
+    postd = O.gp_fit(X * 4, y, kernel, lam * 4, 1.3, 0.05, discrete=[True, False, False])
+    _, _, dmud, dvard = O.gp_mean_and_var_grad(postd, Xs * 4)
+    assert np.all(dmud[0] == 0) and np.all(dvard[0] == 0) and np.any(dmud[1] != 0)
+
+
+def test_acquisition_gradient_restatement_against_finite_differences():
+    """ei_acquisition_grad (EI × feasibility, two constrained outputs, prior-mean gradient) against
+    central finite differences of ei_acquisition."""
+    rng = np.random.default_rng(12)
+    d, N, M, P = 2, 35, 9, 2
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), X[0] - X[1]])
+    lam = [np.array([0.4, 0.6]), np.array([0.5, 0.5])]
+    mean_f = [lambda Z: 0.1 + 0.2 * Z[0], lambda Z: -0.1 * Z[1]]
+    mean_g = [np.array([0.2, 0.0]), np.array([0.0, -0.1])]
+    posts = [O.gp_fit(X, Y[p], "matern52", lam[p], 1.0 + 0.2 * p, 0.05, mean=mean_f[p](X)) for p in range(P)]
+    Xs = rng.uniform(0.05, 0.95, (d, M))
+    y_max = [np.inf, 0.3]
+    coefs = [1.0, 0.2]
+    b = O.best_so_far(coefs, Y, y_max)
+    ms = lambda Z: [mean_f[p](Z) for p in range(P)]
+    mgs = [np.repeat(mean_g[p][:, None], M, axis=1) for p in range(P)]
+    for ym, bb in ((y_max, b), (None, b), (y_max, None)):
+        acq, dacq = O.ei_acquisition_grad(posts, Xs, coefs, ym, bb, means_s=ms(Xs), mean_grads_s=mgs)
+        ref = O.ei_acquisition(posts, Xs, coefs, ym, bb, means_s=ms(Xs))
+        assert np.allclose(acq, ref, rtol=0, atol=1e-14)
+        eps = 1e-6
+        for k in range(d):
+            Xp, Xm = Xs.copy(), Xs.copy()
+            Xp[k] += eps
+            Xm[k] -= eps
+            fd = (O.ei_acquisition(posts, Xp, coefs, ym, bb, means_s=ms(Xp)) -
+                  O.ei_acquisition(posts, Xm, coefs, ym, bb, means_s=ms(Xm))) / (2 * eps)
+            assert np.allclose(dacq[k], fd, rtol=1e-5, atol=1e-8), (ym, bb, k)
