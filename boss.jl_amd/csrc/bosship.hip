@@ -245,8 +245,8 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
             const int m2 = nblk - (k + 2);                   // block triangle behind the pair
             if (m2 > 0) {
                 ProfScope ps(c, "potrf_syrk");
-                hipLaunchKernelGGL(potrf_syrk_kernel, dim3((m2 * (m2 + 1) / 2 + m2) * batch, 1, 1), dim3(256), 0, s, A, ld, bstride,
-                                   k, k + 2, m2, 2, batch);
+                hipLaunchKernelGGL(potrf_syrk_kernel<2>, dim3((m2 * (m2 + 1) / 2 + m2) * batch, 1, 1), dim3(256), 0, s, A, ld, bstride,
+                                   k, k + 2, m2, batch);
             } else if (m2 == 0 && k + 1 < nblk) {
                 // the pair ends the matrix: only the δ^T rows behind it are left (their solve rides in solve_{k+1},
                 // but panel k's contribution to the δ^T entries of block column k+1 was applied by colupd) — nothing to do
@@ -293,8 +293,8 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         }
         if (!la) {
             ProfScope ps(c, "potrf_syrk");
-            hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m * (m + 1) / 2 + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
-                               k + 1, m, 1, 0);
+            hipLaunchKernelGGL(potrf_syrk_kernel<1>, dim3(m * (m + 1) / 2 + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
+                               k + 1, m, 0);
             continue;
         }
         // ---- look-ahead: panel chain on `s`, bulk of the trailing update on the side stream ----------
@@ -310,8 +310,8 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
             (void)hipEventRecord(c->ev_panel[k], s);
             (void)hipStreamWaitEvent(c->side_stream, c->ev_panel[k], 0);
             if (exp_norest != 2)
-                hipLaunchKernelGGL(potrf_syrk_kernel, dim3(m2 * (m2 + 1) / 2 + m2, 1, batch), dim3(256), 0, c->side_stream, A,
-                                   ld, bstride, k, k + 2, m2, 1, 0);
+                hipLaunchKernelGGL(potrf_syrk_kernel<1>, dim3(m2 * (m2 + 1) / 2 + m2, 1, batch), dim3(256), 0, c->side_stream, A,
+                                   ld, bstride, k, k + 2, m2, 0);
             (void)hipEventRecord(c->ev_rest[k], c->side_stream);
             last_rest = k;
         }

@@ -374,8 +374,10 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k,
 //                       panel (first = k+2) — runs on the side stream, 128×128 tiles;
 //   potrf_colupd_kernel only block column k+1 (the next panel), 32×128 tiles so that this short
 //                       kernel on the critical path is one small round.
+template <int NPAN>
 __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                            int first, int m, int npan, int batch1d) {
+                                                            int first, int m, int batch1d) {
+    constexpr int npan = NPAN;                              // compile-time K keeps the tile loop inside the register budget
     // npan adjacent panels k..k+npan-1 applied in one pass (K = 128·npan): the batched schedule pairs
     // panels so every trailing tile is read and written half as often.
     // batch1d > 0: the whole batch is ONE 1-D grid (tiles of matrix 0, then of matrix 1, ...) and
