@@ -12,4 +12,4 @@ from .problem import (BossOptions, BossProblem, Dirac, Domain, ExperimentData, E
                       LinFitness, LogNormal, MvDirac, MvLogNormal, NonlinFitness)
 from .model import HipGaussianProcess, HipGPParams, average_mean  # noqa: F401,E402
 from .fitter import HipBatchedMAP, MAPParams  # noqa: F401,E402
-from .maximizer import HipBatchAM, HipSequentialBatchAM  # noqa: F401,E402
+from .maximizer import HipBatchAM, HipGradientAM, HipSequentialBatchAM  # noqa: F401,E402

@@ -162,4 +162,21 @@ function maximize_acquisition(sb::HipSequentialBatchAM, problem::BOSS.BossProble
     end)
     return X, nothing
 end
+# ---------------------------------------------------------------- analytic gradients (instead of ForwardDiff duals)
+# value and gradient of the acquisition at the columns of X (d×M), one device call for all columns:
+function acq_value_and_grad(problem::BOSS.BossProblem, post, X::AbstractMatrix{<:Real})
+    ei = problem.acquisition::BOSS.ExpectedImprovement{<:BOSS.LinFitness}
+    P = BOSS.y_dim(problem); Xs = Matrix{Float64}(X); d, M = size(Xs)
+    hs = Ptr{Cvoid}[post.slices[p].h for p in 1:P]
+    b = BOSS.best_so_far(problem, ei.fitness)
+    mask = UInt8[BOSS.in_bounds(x, problem.domain.bounds) && BOSS.in_cons(x, problem.domain.cons) for x in eachcol(Xs)]
+    acq = Vector{Float64}(undef, M); dacq = Matrix{Float64}(undef, d, M)
+    check(ccall((:boss_acq_ei_grad, lib), Cint,
+        (Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble,
+         Ptr{UInt8}, Ptr{Cdouble}, Ptr{Cdouble}),
+        P, hs, M, Xs, C_NULL #= [p][M] prior means =#, C_NULL #= [p][d×M] prior-mean gradients =#,
+        Float64.(ei.fitness.coefs), Float64[isinf(c) ? Inf : c for c in problem.y_max], isnothing(b) ? 0 : 1,
+        something(b, 0.0), ei.cons_safe ? mask : C_NULL, acq, dacq))
+    return acq, dacq          # feed an Optimization.jl OptimizationFunction(f; grad = ...) per start, or batch the starts
+end
 end # module

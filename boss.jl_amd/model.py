@@ -195,6 +195,14 @@ class HipGaussianProcessPosteriorSlice:
         mu, var = self.mean_and_var(x)
         return mu, np.sqrt(var)
 
+    def mean_and_var_grad(self, X, mean_grad=None):
+        """mean_and_var(post, X) with its gradient w.r.t. the columns of X (analytic, on the device):
+        (mu[M], var[M], dmu[d,M], dvar[d,M]).  mean_grad: d×M gradient of the prior mean, if it has one."""
+        X = np.asarray(X, float)
+        if X.ndim == 1:
+            X = X[:, None]
+        return self.gp.predict_grad(X, self._mean_s(X), mean_grad)
+
     def mean_and_cov(self, X):
         """mean_and_cov(post, X::Matrix) (gaussian_process.jl:180-184) -> (mu[M], Σ[M,M])."""
         X = np.asarray(X, float)

@@ -717,6 +717,36 @@ def test_acquisition_gradient(api, O, mode):
         g.close()
 
 
+def test_gradient_maximizer_beats_its_starts_and_matches_a_dense_grid(api, O):
+    """HipGradientAM (OptimizationAM semantics with device gradients): from 40 random starts it reaches
+    the acquisition's global maximum found by a dense grid (2-D problem), stays inside the domain, and
+    never returns less than the best start."""
+    import boss_jl_amd as B
+    rng = np.random.default_rng(4)
+    d, N = 2, 60
+    X = rng.uniform(0, 1, (d, N))
+    Y = (np.sin(5 * X[0]) * np.cos(3 * X[1]) + 0.5 * X[0])[None, :]
+    prm = B.HipGPParams(np.array([[0.25], [0.3]]), [1.0], [0.02])
+    model = B.HipGaussianProcess([None], [None], [None])
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness([1.0])), model,
+                         B.ExperimentData(X, Y), None, prm)
+    am = B.HipGradientAM(x_prior=lambda r: r.uniform(0, 1, d), multistart=40, iters=40, seed=2)
+    x, val = am.maximize_acquisition(prob)
+    assert x.shape == (d,) and np.all(x >= 0) and np.all(x <= 1)
+    # dense grid through the oracle
+    post = O.gp_fit(X, Y[0], "matern52", prm.lengthscales[:, 0], 1.0, 0.02)
+    gx = np.linspace(0, 1, 201)
+    G = np.asfortranarray(np.stack(np.meshgrid(gx, gx, indexing="ij")).reshape(2, -1))
+    b = float(Y.max())
+    ag = O.ei_acquisition([post], G, [1.0], [np.inf], b)
+    assert val >= ag.max() * (1 - 1e-3) - 1e-12, (val, ag.max())
+    a_x = O.ei_acquisition([post], x[:, None], [1.0], [np.inf], b)[0]
+    assert abs(a_x - val) <= 1e-10
+    starts_rng = np.random.default_rng(2)
+    S0 = np.stack([starts_rng.uniform(0, 1, d) for _ in range(40)], axis=1)
+    assert val >= O.ei_acquisition([post], S0, [1.0], [np.inf], b).max() - 1e-12
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
