@@ -130,6 +130,19 @@ def _shard_modes(B, D, MX, O, rank, world):
     assert np.array_equal(x, Xs[:, j]) and abs(val - full[j]) <= 1e-15 * (1 + abs(full[j]))
     _, allv = am.maximize_acquisition(prob, return_all=True)
     assert np.allclose(allv, full, rtol=0, atol=1e-15)
+    # ---- gradient multistart: starts sharded across ranks, identical winner on every rank
+    post1 = O.gp_fit(X, Y[0], "matern52", [0.4, 0.5], 1.0, 0.05)
+    bb = float(Y[0].max())
+
+    def fake_vg(self, problem, posts, Xc):
+        return O.ei_acquisition_grad([post1], Xc, [1.0], None, bb, valid_mask=O.in_bounds(Xc, np.zeros(d), np.ones(d)))
+
+    B.HipGradientAM._value_and_grad = fake_vg
+    gam = B.HipGradientAM(x_prior=lambda r: r.uniform(0, 1, d), multistart=11, iters=15, seed=9)
+    xg, vg = gam.maximize_acquisition(prob, posts=[None])
+    both = D.allgather_concat(np.concatenate([xg, [vg]]))
+    assert np.array_equal(both[:d + 1], both[d + 1:]), both          # same answer on both ranks
+    assert abs(O.ei_acquisition([post1], xg[:, None], [1.0], None, bb)[0] - vg) <= 1e-12
     # ---- raw collectives
     tot = D.allreduce_sum(np.arange(4.0) + rank)
     assert np.array_equal(tot, world * np.arange(4.0) + sum(range(world)))
