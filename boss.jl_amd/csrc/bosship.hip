@@ -60,7 +60,7 @@ struct Ctx {
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
-    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc;
+    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw;   // craw: raw candidates of one-shot calls
     void* pinned = nullptr;   // small host-pinned result area
     std::mutex mtx;
 };
@@ -892,6 +892,24 @@ extern "C" int boss_cand_create(int device, int d, int M, const double* Xs, boss
     return BOSS_OK;
 }
 
+// One-shot entry points (predict / predict_cov / predict_grad / acq_ei_grad) upload their candidates into a
+// grow-only per-device workspace instead of allocating: hipMalloc/hipFree synchronise the device and cost
+// a few hundred microseconds per call.  Caller holds the context lock.
+static int temp_cand(Ctx* c, int d, int M, const double* Xs, boss_cand* cd) {
+    cd->ctx = c;
+    cd->d = d;
+    cd->M = M;
+    cd->Mp = round_up(M, 64);
+    int rc = ws_reserve(c->craw, sizeof(double) * (size_t)d * cd->Mp);
+    if (rc) return rc;
+    cd->Craw = (double*)c->craw.p;
+    std::vector<double> buf;
+    pack_points(buf, Xs, d, M, cd->Mp, nullptr);
+    HIPCHK(hipMemcpyAsync(cd->Craw, buf.data(), sizeof(double) * d * cd->Mp, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));               // staging buffer goes out of scope
+    return BOSS_OK;
+}
+
 extern "C" void boss_cand_free(boss_cand_t* cd) {
     if (!cd) return;
     if (cd->ctx) {
@@ -967,21 +985,18 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);                 // the per-device scratch areas are shared
-    boss_cand_t* cd = nullptr;
-    int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
+    boss_cand cand_tmp;
+    boss_cand* cd = &cand_tmp;
+    int rc = temp_cand(c, g->d, M, Xs, cd);
     if (rc) return rc;
-    double* dev = nullptr;   // mu | var | mean | bad
-    if (hipMalloc((void**)&dev, sizeof(double) * (3 * (size_t)M + 2)) != hipSuccess) {
-        boss_cand_free(cd);
-        return fail(BOSS_E_ALLOC, "device allocation failed");
-    }
+    rc = ws_reserve(c->pred, sizeof(double) * (3 * (size_t)M + 2));   // mu | var | mean | bad
+    if (rc) return rc;
+    double* dev = (double*)c->pred.p;
     double *dmu = dev, *dvar = dev + M, *dmean = dev + 2 * (size_t)M;
     unsigned long long* dbad = (unsigned long long*)(dev + 3 * (size_t)M);
     hipStream_t s = c->stream;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(s);
-        (void)hipFree(dev);
-        boss_cand_free(cd);
     };
     if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * M, hipMemcpyHostToDevice, s);
     (void)hipMemsetAsync(dbad, 0xff, sizeof(unsigned long long), s);
@@ -1075,24 +1090,21 @@ extern "C" int boss_gp_predict_grad(boss_gp_t* g, int M, const double* Xs, const
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);
-    boss_cand_t* cd = nullptr;
-    int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
+    boss_cand cand_tmp;
+    boss_cand* cd = &cand_tmp;
+    int rc = temp_cand(c, g->d, M, Xs, cd);
     if (rc) return rc;
     const int d = g->d;
     const size_t dm = (size_t)d * M;
-    double* dev = nullptr;   // mu | var | mean | mean_grad | dmu | dvar | bad
-    if (hipMalloc((void**)&dev, sizeof(double) * (3 * (size_t)M + 3 * dm + 2)) != hipSuccess) {
-        boss_cand_free(cd);
-        return fail(BOSS_E_ALLOC, "device allocation failed");
-    }
+    rc = ws_reserve(c->pred, sizeof(double) * (3 * (size_t)M + 3 * dm + 2));   // mu | var | mean | mean_grad | dmu | dvar | bad
+    if (rc) return rc;
+    double* dev = (double*)c->pred.p;
     double *dmu_ = dev, *dvar_ = dev + M, *dmean = dev + 2 * (size_t)M, *dmg = dev + 3 * (size_t)M;
     double *dgm = dmg + dm, *dgv = dgm + dm;
     unsigned long long* dbad = (unsigned long long*)(dgv + dm);
     hipStream_t s = c->stream;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(s);
-        (void)hipFree(dev);
-        boss_cand_free(cd);
     };
     if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * M, hipMemcpyHostToDevice, s);
     if (mean_grad) (void)hipMemcpyAsync(dmg, mean_grad, sizeof(double) * dm, hipMemcpyHostToDevice, s);
@@ -1139,19 +1151,17 @@ extern "C" int boss_acq_ei_grad(int P, boss_gp_t* const* gps, int M, const doubl
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);
     const int d = gps[0]->d;
-    boss_cand_t* cd = nullptr;
-    int rc = boss_cand_create(c->device, d, M, Xs, &cd);
+    boss_cand cand_tmp;
+    boss_cand* cd = &cand_tmp;
+    int rc = temp_cand(c, d, M, Xs, cd);
     if (rc) return rc;
     hipStream_t s = c->stream;
     const size_t dm = (size_t)d * M;
     // device scratch: mu[P][M] | var[P][M] | mean[P][M] | mean_grad[P][dM] | dmu[P][dM] | dvar[P][dM] | acq[M] | dacq[dM] | coefs[P] | ymax[P] | mask
     const size_t nd = (size_t)3 * P * M + (size_t)3 * P * dm + M + dm + 2 * P;
-    double* dev = nullptr;
-    if (hipMalloc((void**)&dev, sizeof(double) * nd + M) != hipSuccess) {
-        boss_cand_free(cd);
-        (void)hipGetLastError();
-        return fail(BOSS_E_ALLOC, "device allocation failed");
-    }
+    rc = ws_reserve(c->pred, sizeof(double) * nd + M);
+    if (rc) return rc;
+    double* dev = (double*)c->pred.p;
     double* dmu = dev;
     double* dvar = dmu + (size_t)P * M;
     double* dmean = dvar + (size_t)P * M;
@@ -1165,8 +1175,6 @@ extern "C" int boss_acq_ei_grad(int P, boss_gp_t* const* gps, int M, const doubl
     unsigned char* dmask = (unsigned char*)(dev + nd);
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(s);
-        (void)hipFree(dev);
-        boss_cand_free(cd);
     };
     EiPar par;
     rc = ei_params(c, s, P, fit_coefs, y_max, has_best, best, &par, dcoef, dymax);
