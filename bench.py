@@ -217,6 +217,27 @@ def main():
                       "serialised_ms_diag": ms_diag / reps, "serialised_ms_trsm": ms_trsm / reps,
                       "serialised_ms_syrk": ms_syrk / reps}
 
+    # ---- SURVEY §8f rows built beyond the headline path (rank 0, N=1 only; a fraction of a second)
+    extras = None
+    if rank == 0 and world == 1:
+        gp.update(lam, 1.0, 0.05)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            gp.predict_grad(Xs)
+        t_grad = (time.perf_counter() - t0) / 3
+        rng = np.random.default_rng(7)
+        g2 = api.GP(X, y, KERNEL, device=dev)
+        g2.update(lam, 1.0, 0.05)
+        g2.append(rng.uniform(0, 1, D), 0.0)                       # first append grows the storage
+        t0 = time.perf_counter()
+        for _ in range(8):
+            g2.append(rng.uniform(0, 1, D), 0.0)
+        t_app = (time.perf_counter() - t0) / 8
+        g2.close()
+        extras = {"block_cholesky_append_ms": t_app * 1e3,
+                  "append_vs_refactorisation": (t_upd / args.steps) / t_app,
+                  "posterior_gradient_evals_per_sec": M_CAND / t_grad, "ms_gradient_batch": t_grad * 1e3}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(X, y, Xs, lam)
@@ -239,7 +260,7 @@ def main():
                        "parallelism": f"{world} independent GP slices + candidate shards, 16-byte RCCL arg-max all-gather"},
             "frac_of_fp64_mfma_roofline": {"update": flops_update(N_OBS, D) * upd_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12),
                                            "acq": flops_acq_eval(N_OBS, D) * acq_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12)},
-            "roofline": roof, "roofline_potrf": roof_potrf, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_potrf": roof_potrf, "cpu_baseline": cpu, "next_rows": extras,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

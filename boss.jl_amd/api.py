@@ -37,6 +37,7 @@ SIGNATURES = {
     "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
                               _c_ucp, C.POINTER(C.c_void_p), _c_dp]),
     "boss_gp_set_y": (C.c_int, [C.c_void_p, _c_dp]),
+    "boss_gp_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "boss_gp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_gp_free": (None, [C.c_void_p]),
     "boss_gp_get_factor": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
@@ -54,6 +55,12 @@ SIGNATURES = {
                                       C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
     "boss_acq_ei_grad": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
                                    C.c_double, _c_ucp, _c_dp, _c_dp]),
+    "boss_track_create": (C.c_int, [C.c_void_p, C.c_void_p, _c_dp, C.POINTER(C.c_void_p)]),
+    "boss_track_free": (None, [C.c_void_p]),
+    "boss_track_sync": (C.c_int, [C.c_void_p]),
+    "boss_track_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_dp, _c_dp]),
+    "boss_acq_ei_tracks": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), _c_dp, _c_dp, C.c_int, C.c_double, _c_ucp,
+                                     _c_dp, C.POINTER(C.c_long), _c_dp]),
     "boss_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _c_dp]),
     "boss_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "boss_prof_reset": (C.c_int, [C.c_int]),
@@ -189,6 +196,11 @@ class GP:
         y = _f64(np.asarray(y).reshape(-1), 1)
         _check(load_library().boss_gp_set_y(self._h, _dp(y)))
 
+    def reserve(self, N_total: int):
+        """Reserve storage for N_total observations (later appends need no re-allocation); the handle
+        must be (re-)updated afterwards."""
+        _check(load_library().boss_gp_reserve(self._h, int(N_total)))
+
     def append(self, X_new, y_new, mean_new=None) -> float:
         """augment_dataset! + model_posterior with unchanged hyper-parameters (block Cholesky
         append): X_new d×n (or a length-d vector), y_new n.  Returns the logpdf of all N+n points."""
@@ -316,8 +328,15 @@ class Candidates:
             pass
 
 
-def fit(X, y, kernel, lengthscale, amplitude, noise_std, mean_X=None, discrete=None, device: int = 0) -> GP:
-    """posterior_gp (gaussian_process.jl:199-211) through the one-shot boss_gp_fit entry point."""
+def fit(X, y, kernel, lengthscale, amplitude, noise_std, mean_X=None, discrete=None, device: int = 0,
+        reserve: int = 0) -> GP:
+    """posterior_gp (gaussian_process.jl:199-211) through the one-shot boss_gp_fit entry point.
+    reserve > 0: room for that many later appends (create + reserve + update instead)."""
+    if reserve > 0:
+        g = GP(X, y, kernel, discrete, device)
+        g.reserve(g.N + reserve)
+        g.update(lengthscale, amplitude, noise_std, mean_X)
+        return g
     lib = load_library()
     X = _f64(X, 2)
     y = _f64(np.asarray(y).reshape(-1), 1)
@@ -390,6 +409,61 @@ def acq_ei(gps: Sequence[Sequence[GP]], cand: Candidates, fit_coefs, y_max=None,
     _check(load_library().boss_acq_ei(P, S, arr, cand._h, _dp(ms), _dp(coefs), _dp(ym), 0 if best is None else 1,
                                       0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am),
                                       C.byref(mx)))
+    return acq, am.value, mx.value
+
+
+class Track:
+    """Resident predictive state of one posterior at one candidate set (boss_track_t): after
+    GP.append the moments are extended in O(N·M) instead of re-solved.  Keep `gp` and `cand` alive."""
+
+    def __init__(self, gp: GP, cand: Candidates, mean_Xs=None):
+        ms = None if mean_Xs is None else _f64(np.asarray(mean_Xs).reshape(-1), 1)
+        if ms is not None and ms.shape[0] != cand.M:
+            raise ValueError("mean_Xs must have one entry per candidate")
+        h = C.c_void_p()
+        _check(load_library().boss_track_create(gp._h, cand._h, _dp(ms), C.byref(h)))
+        self._h, self.gp, self.cand, self.M = h, gp, cand, cand.M
+
+    def sync(self):
+        _check(load_library().boss_track_sync(self._h))
+
+    def moments(self, first: int = 0, count: Optional[int] = None):
+        """(mu, var) of candidates [first, first+count) — var unclipped (apply _clip_var yourself)."""
+        count = self.M - first if count is None else count
+        mu, var = np.zeros(count), np.zeros(count)
+        _check(load_library().boss_track_moments(self._h, first, count, _dp(mu), _dp(var)))
+        return mu, var
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().boss_track_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def acq_ei_tracks(tracks: Sequence[Sequence[Track]], fit_coefs, y_max=None, best=None, valid_mask=None,
+                  want_acq: bool = True):
+    """acq_ei on tracked states: tracks[s][p] = output p of hyper-parameter sample s."""
+    S, P = len(tracks), len(tracks[0])
+    arr = (C.c_void_p * (P * S))()
+    for s in range(S):
+        for p in range(P):
+            arr[p + P * s] = tracks[s][p]._h
+    M = tracks[0][0].M
+    coefs = _f64(np.asarray(fit_coefs).reshape(-1), 1)
+    ym = None if y_max is None else _f64(np.asarray(y_max).reshape(-1), 1)
+    mask = None if valid_mask is None else np.ascontiguousarray(np.asarray(valid_mask, dtype=bool).astype(np.uint8))
+    acq = np.zeros(M) if want_acq else None
+    am = C.c_long(-1)
+    mx = C.c_double(0.0)
+    _check(load_library().boss_acq_ei_tracks(P, S, arr, _dp(coefs), _dp(ym), 0 if best is None else 1,
+                                             0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am),
+                                             C.byref(mx)))
     return acq, am.value, mx.value
 
 

@@ -165,6 +165,7 @@ struct boss_gp {
     double* host_res = nullptr;                // pinned: scal[2], info
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
+    unsigned long long epoch = 0;              // bumped by every boss_gp_update: tracked candidate states go stale
     hipEvent_t dinv_ev = nullptr;              // the side stream finished building Dinv / Dinv2
     bool dinv_pending = false;
 };
@@ -173,6 +174,15 @@ struct boss_cand {
     Ctx* ctx = nullptr;
     int d = 0, M = 0, Mp = 0;
     double* Craw = nullptr;                    // [d][Mp]
+};
+
+struct boss_track {                            // resident predictive state of (posterior, candidate set)
+    Ctx* ctx = nullptr;
+    boss_gp* gp = nullptr;
+    int d = 0, M = 0, Mp = 0, tiles = 0, Ncap = 0, N = 0;
+    unsigned long long epoch = 0;
+    double *V = nullptr, *Csc = nullptr, *mu = nullptr, *var = nullptr, *mean = nullptr;
+    bool has_mean = false;
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -538,6 +548,7 @@ extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double am
     g->fitted = false;
     g->have_dinv = false;
     g->have_lt = false;
+    ++g->epoch;
     // +1e-8 on every parameter (gaussian_process.jl:239-241)
     HIPCHK(hipEventSynchronize(g->par_ev));   // previous update's staging copies have been consumed
     double* invlam = g->host_par;
@@ -627,6 +638,22 @@ static int gp_grow(boss_gp* g, int Nnew) {
     g->ld = ld2;
     g->have_dinv = false;
     g->have_lt = false;
+    return BOSS_OK;
+}
+
+// Reserve storage for observations that will be appended later (no re-allocation / re-layout when
+// they arrive).  The extra rows are identity padding of the factor: harmless, a little extra work per
+// factorisation.  The handle is left unfitted: call boss_gp_update afterwards.
+extern "C" int boss_gp_reserve(boss_gp_t* g, int N_total) {
+    if (!g || N_total < 1) return fail(BOSS_E_INVALID, "bad arguments");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    if (g->pending) (void)gp_finish(g, nullptr);
+    int rc = gp_grow(g, N_total);
+    if (rc) return rc;
+    g->fitted = false;
+    ++g->epoch;
     return BOSS_OK;
 }
 
@@ -1394,6 +1421,192 @@ extern "C" int boss_acq_ei_moments(int device, int P, int S, int M, const double
                            dcoef, dymax, dacq);
     hipLaunchKernelGGL(acq_epilogue_kernel, dim3(1), dim3(ACQ_EPI_THREADS), 0, s, dmu + pm * (S - 1), dvar + pm * (S - 1), M, M,
                        par, dcoef, dymax, dacq, S > 1 ? 1 : 0, 1.0 / S, valid_mask ? dmask : nullptr, hres);
+    if (acq_out) (void)hipMemcpyAsync(acq_out, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (argmax_out) std::memcpy(argmax_out, &hres[1], sizeof(long));
+    if (max_out) *max_out = hres[0];
+    return BOSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tracked candidates: resident V slabs, updated in O(N·M) per appended observation
+// ------------------------------------------------------------------------------------------
+static void track_release(boss_track* t) {
+    if (!t) return;
+    if (t->ctx) (void)hipSetDevice(t->ctx->device);
+    void* ptrs[] = {t->V, t->Csc, t->mu, t->var, t->mean};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete t;
+}
+
+// (re)build the whole state with the prediction kernel; caller holds the context lock
+static int track_rebuild(boss_track* t, const boss_cand* cd) {
+    boss_gp* g = t->gp;
+    Ctx* c = t->ctx;
+    hipStream_t s = c->stream;
+    const int Ncap = g->Np + PRED_RB;
+    if (Ncap > t->Ncap) {
+        if (t->V) (void)hipFree(t->V);
+        t->V = nullptr;
+        if (hipMalloc((void**)&t->V, sizeof(double) * (size_t)t->tiles * Ncap * 32) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(BOSS_E_ALLOC, "device allocation failed (tracked V slabs)");
+        }
+        t->Ncap = Ncap;
+    }
+    int rc = predict_enqueue(g, cd, t->has_mean ? t->mean : nullptr, t->mu, t->var, true);   // 32-wide slabs in the scratch
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2DAsync(t->V, sizeof(double) * (size_t)t->Ncap * 32, c->vscratch.p, sizeof(double) * (size_t)g->Np * 32,
+                            sizeof(double) * (size_t)g->Np * 32, t->tiles, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(t->Csc, c->csc.p, sizeof(double) * (size_t)t->d * t->Mp, hipMemcpyDeviceToDevice, s));
+    t->N = g->N;
+    t->epoch = g->epoch;
+    return BOSS_OK;
+}
+
+extern "C" int boss_track_create(boss_gp_t* g, const boss_cand_t* cand, const double* mean_Xs, boss_track_t** out) {
+    if (!out) return fail(BOSS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!g || !cand) return fail(BOSS_E_INVALID, "NULL argument");
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    if (cand->ctx != g->ctx || cand->d != g->d) return fail(BOSS_E_INVALID, "candidates and posterior must share device and x_dim");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    boss_track* t = new boss_track();
+    t->ctx = c;
+    t->gp = g;
+    t->d = g->d;
+    t->M = cand->M;
+    t->Mp = cand->Mp;
+    t->tiles = (cand->M + 31) / 32;
+    if (hipMalloc((void**)&t->Csc, sizeof(double) * (size_t)t->d * t->Mp) != hipSuccess ||
+        hipMalloc((void**)&t->mu, sizeof(double) * t->M) != hipSuccess ||
+        hipMalloc((void**)&t->var, sizeof(double) * t->M) != hipSuccess ||
+        hipMalloc((void**)&t->mean, sizeof(double) * t->M) != hipSuccess) {
+        (void)hipGetLastError();
+        track_release(t);
+        return fail(BOSS_E_ALLOC, "device allocation failed");
+    }
+    if (mean_Xs) {
+        HIPCHK(hipMemcpyAsync(t->mean, mean_Xs, sizeof(double) * t->M, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        t->has_mean = true;
+    }
+    int rc = track_rebuild(t, cand);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        track_release(t);
+        return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = t;
+    return BOSS_OK;
+}
+
+extern "C" void boss_track_free(boss_track_t* t) {
+    if (!t) return;
+    if (t->ctx) {
+        (void)hipSetDevice(t->ctx->device);
+        (void)hipStreamSynchronize(t->ctx->stream);
+    }
+    track_release(t);
+}
+
+// bring the state up to the posterior's current N (enqueue only); caller holds the context lock
+static int track_sync_locked(boss_track* t) {
+    boss_gp* g = t->gp;
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "the tracked posterior has no valid factorisation");
+    if (t->epoch != g->epoch)
+        return fail(BOSS_E_INVALID, "the tracked posterior was re-fitted with new hyper-parameters: create a new track");
+    if (g->N < t->N) return fail(BOSS_E_INVALID, "the tracked posterior shrank");
+    if (g->N > t->Ncap) return fail(BOSS_E_INVALID, "tracked state out of capacity: create a new track");
+    hipStream_t s = t->ctx->stream;
+    for (int N0 = t->N; N0 < g->N; N0 += TRACK_ROWS) {
+        const int n = std::min(TRACK_ROWS, g->N - N0);
+        hipLaunchKernelGGL(track_append_kernel, dim3(t->tiles), dim3(256), 0, s, (const double*)g->A, g->ld, g->Np, N0, n, t->V,
+                           t->Ncap, (const double*)g->Xsc, g->Np, (const double*)t->Csc, t->d, t->Mp, t->M, g->kernel, g->amp2,
+                           t->mu, t->var);
+    }
+    t->N = g->N;
+    HIPCHK(hipGetLastError());
+    return BOSS_OK;
+}
+
+extern "C" int boss_track_sync(boss_track_t* t) {
+    if (!t) return fail(BOSS_E_INVALID, "track is NULL");
+    Ctx* c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = track_sync_locked(t);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BOSS_OK;
+}
+
+extern "C" int boss_track_moments(boss_track_t* t, int first, int count, double* mu, double* var) {
+    if (!t || !mu || !var || first < 0 || count < 1 || first + count > t->M) return fail(BOSS_E_INVALID, "bad arguments");
+    Ctx* c = t->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = track_sync_locked(t);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(mu, t->mu + first, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(var, t->var + first, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BOSS_OK;
+}
+
+extern "C" int boss_acq_ei_tracks(int P, int S, boss_track_t* const* tracks, const double* fit_coefs, const double* y_max,
+                                  int has_best, double best, const unsigned char* valid_mask, double* acq_out,
+                                  long* argmax_out, double* max_out) {
+    if (P < 1 || S < 1 || !tracks || !fit_coefs) return fail(BOSS_E_INVALID, "bad arguments");
+    for (int i = 0; i < P * S; ++i) {
+        if (!tracks[i]) return fail(BOSS_E_INVALID, "NULL track");
+        if (tracks[i]->ctx != tracks[0]->ctx || tracks[i]->M != tracks[0]->M)
+            return fail(BOSS_E_INVALID, "all tracks must share the device and the candidate set");
+    }
+    Ctx* c = tracks[0]->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    hipStream_t s = c->stream;
+    const int M = tracks[0]->M;
+    const size_t nd = (size_t)2 * P * M + M + 2 * P;
+    int rc = ws_reserve(c->acq, sizeof(double) * nd + M);
+    if (rc) return rc;
+    double* dev = (double*)c->acq.p;
+    double* dmu = dev;
+    double* dvar = dmu + (size_t)P * M;
+    double* dacq = dvar + (size_t)P * M;
+    double* dcoef = dacq + M;
+    double* dymax = dcoef + P;
+    unsigned char* dmask = (unsigned char*)(dev + nd);
+    double* hres = (double*)c->pinned;
+    EiPar par;
+    rc = ei_params(c, s, P, fit_coefs, y_max, has_best, best, &par, dcoef, dymax);
+    if (rc) return rc;
+    if (valid_mask) (void)hipMemcpyAsync(dmask, valid_mask, M, hipMemcpyHostToDevice, s);
+    if (S > 1) (void)hipMemsetAsync(dacq, 0, sizeof(double) * M, s);
+    for (int sm = 0; sm < S; ++sm) {
+        for (int p = 0; p < P; ++p) {
+            boss_track* t = tracks[p + (size_t)P * sm];
+            rc = track_sync_locked(t);
+            if (rc) {
+                (void)hipStreamSynchronize(s);
+                return rc;
+            }
+            (void)hipMemcpyAsync(dmu + (size_t)p * M, t->mu, sizeof(double) * M, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(dvar + (size_t)p * M, t->var, sizeof(double) * M, hipMemcpyDeviceToDevice, s);
+        }
+        if (sm + 1 < S)
+            hipLaunchKernelGGL(ei_accumulate_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dmu, dvar, M, M, par, dcoef, dymax,
+                               dacq);
+        else
+            hipLaunchKernelGGL(acq_epilogue_kernel, dim3(1), dim3(ACQ_EPI_THREADS), 0, s, dmu, dvar, M, M, par, dcoef, dymax,
+                               dacq, S > 1 ? 1 : 0, 1.0 / S, valid_mask ? dmask : nullptr, hres);
+    }
     if (acq_out) (void)hipMemcpyAsync(acq_out, dacq, sizeof(double) * M, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));

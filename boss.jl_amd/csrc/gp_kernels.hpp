@@ -500,6 +500,73 @@ __global__ __launch_bounds__(256) void grad_accum_kernel(const double* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Tracked candidates (boss_track_t): the V = L⁻¹K* slabs of a fixed candidate set stay resident, so
+// after boss_gp_append the predictive moments are UPDATED instead of re-solved — per new observation
+// r one more row of V,   v_r = (k(x_r, x*) − Σ_{i<r} L[r,i] V[i,·]) / L[r,r] ,   σ² −= v_r² ,  μ += v_r z_r ,
+// an O(N·M) pass over the slabs (≈0.25 GB at N=4096, M=8192) instead of the O(N²M) substitution.
+// Up to 8 new rows per launch (one read of V for all of them).  One workgroup per 32-candidate slab:
+// lanes along the candidates, 8 subsets of the old rows; the new rows of L are staged through LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int TRACK_ROWS = 8;
+__global__ __launch_bounds__(256) void track_append_kernel(const double* __restrict__ A, int ld, int Np, int N0, int n,
+                                                           double* __restrict__ Vslabs, int Ncap,
+                                                           const double* __restrict__ Xsc, int Npx,
+                                                           const double* __restrict__ Csc, int d, int Mp, int M, int kern,
+                                                           double amp2, double* __restrict__ mu, double* __restrict__ var) {
+    constexpr int BN = 32, CH = 64;
+    __shared__ double Lr[TRACK_ROWS][CH];
+    __shared__ double red[8][TRACK_ROWS][BN];
+    const int tid = threadIdx.x, c = tid & 31, rs = tid >> 5;
+    double* V = Vslabs + (size_t)blockIdx.x * Ncap * BN;
+    double acc[TRACK_ROWS];
+#pragma unroll
+    for (int q = 0; q < TRACK_ROWS; ++q) acc[q] = 0.0;
+    for (int i0 = 0; i0 < N0; i0 += CH) {
+        __syncthreads();
+        for (int idx = tid; idx < TRACK_ROWS * CH; idx += 256) {
+            const int q = idx / CH, ii = idx - q * CH;
+            Lr[q][ii] = (q < n && i0 + ii < N0) ? A[(size_t)(i0 + ii) * ld + N0 + q] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CH / 8; ++k) {
+            const int ii = rs + 8 * k;
+            const double v = (i0 + ii < N0) ? V[(size_t)(i0 + ii) * BN + c] : 0.0;
+#pragma unroll
+            for (int q = 0; q < TRACK_ROWS; ++q) acc[q] = __builtin_fma(Lr[q][ii], v, acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TRACK_ROWS; ++q) red[rs][q][c] = acc[q];
+    __syncthreads();
+    if (rs == 0) {
+        const int j = blockIdx.x * BN + c;
+        double vnew[TRACK_ROWS];
+        double dvar = 0.0, dmu = 0.0;
+        for (int q = 0; q < n; ++q) {
+            double dot = 0.0;
+            for (int k = 0; k < 8; ++k) dot += red[k][q][c];
+            double r2 = 0.0;
+            for (int m = 0; m < d; ++m) {
+                const double diff = Csc[(size_t)m * Mp + j] - Xsc[(size_t)m * Npx + N0 + q];
+                r2 = __builtin_fma(diff, diff, r2);
+            }
+            double t = amp2 * kappa_r2(kern, r2) - dot;
+            for (int qq = 0; qq < q; ++qq) t = __builtin_fma(-A[(size_t)(N0 + qq) * ld + N0 + q], vnew[qq], t);
+            const double v = t / A[(size_t)(N0 + q) * ld + N0 + q];
+            vnew[q] = v;
+            V[(size_t)(N0 + q) * BN + c] = v;
+            dvar = __builtin_fma(v, v, dvar);
+            dmu = __builtin_fma(v, A[(size_t)(N0 + q) * ld + Np], dmu);      // z_r sits in row Np of the factor array
+        }
+        if (j < M) {
+            var[j] -= dvar;
+            mu[j] += dmu;
+        }
+    }
+}
+
 // a5: full posterior covariance  Σ = K** − VᵀV + 1e-18·I  (mean_and_cov, gaussian_process.jl:180-184;
 // AbstractGPs cov(post(X*))) from the V slabs the prediction kernel left in its scratch
 // (V(n, j) = Vs[(j/BN * Np + n) * BN + j % BN]).  16×16 outputs per workgroup, n staged through LDS.

@@ -39,15 +39,16 @@ def _rand_in_domain(x_prior: Callable, domain, rng, max_attempts: int):
     return None
 
 
-def posteriors_of(problem: BossProblem, lo: Optional[int] = None, hi: Optional[int] = None):
+def posteriors_of(problem: BossProblem, lo: Optional[int] = None, hi: Optional[int] = None, reserve: int = 0):
     """model_posterior(problem) (src/posterior.jl:2-3): list over BI samples of posteriors.
-    [lo, hi) restricts the construction to a shard of the samples."""
+    [lo, hi) restricts the construction to a shard of the samples; reserve: room for later appends."""
     params = problem.params
     if lo is not None:
         params = list(params)[lo:hi]
         if not params:
             return []
-    post = problem.model.model_posterior(params, problem.data)
+    post = problem.model.model_posterior(params, problem.data, reserve) if reserve else \
+        problem.model.model_posterior(params, problem.data)
     return post if isinstance(post, list) else [post]
 
 
@@ -201,7 +202,9 @@ class HipSequentialBatchAM:
 
     The reference rebuilds the posterior from scratch (an O(N^3) Cholesky) for every selected
     point; here the posteriors stay resident and each speculative observation is a block Cholesky
-    append (boss_gp_append, O(N^2)) under the unchanged hyper-parameters — same posterior."""
+    append (boss_gp_append, O(N^2)) under the unchanged hyper-parameters — same posterior.  When the
+    inner maximiser's candidate set is fixed (`points`, or a seeded sample) the candidates' predictive
+    state stays resident too (boss_track_*) and is extended in O(N·M) per selection."""
     am: HipBatchAM
     batch_size: int
 
@@ -209,9 +212,13 @@ class HipSequentialBatchAM:
         import copy
         prob = copy.copy(problem)                                        # problem_ = deepcopy(problem) (batch.jl:27)
         prob.data = type(problem.data)(problem.data.X.copy(), problem.data.Y.copy())
-        posts = posteriors_of(prob)
-        xs = []
+        posts = posteriors_of(prob, reserve=self.batch_size)             # no re-allocation when the appends arrive
+        fixed = self.am.points is not None or self.am.seed is not None   # same candidate set at every selection
+        lin = not isinstance(prob.acquisition.fitness, NonlinFitness)
         try:
+            if fixed and lin and self.am.shard == "candidates":
+                return self._tracked(prob, posts), None
+            xs = []
             for _ in range(self.batch_size):                             # speculative_evaluation! (batch.jl:32-38)
                 x, _ = self.am.maximize_acquisition(prob, options, posts=posts)
                 y = sum(p.mean(x) for p in posts) / len(posts)           # mean(post, x); BI: average_mean
@@ -219,10 +226,53 @@ class HipSequentialBatchAM:
                 for p in posts:
                     p.append(x, y)
                 xs.append(x)
+            return np.stack(xs, axis=1), None
         finally:
             for p in posts:
                 p.close()
-        return np.stack(xs, axis=1), None
+
+    def _tracked(self, prob: BossProblem, posts):
+        """Fixed candidate set: the candidates' V slabs stay resident (api.Track) and every speculative
+        observation extends them by one row — O(N·M) per selection instead of the O(N²M) re-solve."""
+        Xs = self.am.candidates(prob)                                    # identical on every rank
+        M = Xs.shape[1]
+        rank, world = dist_util.rank_world(self.am.group)
+        lo, hi = dist_util.shard_range(M, rank, world)
+        ei = prob.acquisition
+        dev = prob.model.device
+        cand = api.Candidates(Xs[:, lo:hi], dev) if hi > lo else None
+        tracks = []
+        if cand is not None:
+            tracks = [[api.Track(s.gp, cand, s._mean_s(Xs[:, lo:hi])) for s in p.slices] for p in posts]
+        mask = None
+        if ei.cons_safe and hi > lo:
+            mask = in_bounds(Xs[:, lo:hi], prob.domain.bounds) & in_cons(Xs[:, lo:hi], prob.domain.cons)
+        xs = []
+        try:
+            for _ in range(self.batch_size):
+                b = best_so_far(ei.fitness, prob.data.Y, prob.y_max)
+                if cand is not None:
+                    _, am, mx = api.acq_ei_tracks(tracks, ei.fitness.coefs, prob.y_max, b, mask, want_acq=False)
+                    am += lo
+                else:
+                    am, mx = M, -np.inf
+                mx, am = dist_util.argmax_exchange(mx, am, self.am.group)
+                x = Xs[:, am].copy()
+                yl = np.zeros(0)
+                if lo <= am < hi:                                        # the owner reads ŷ = mean(post, x) off its tracks
+                    yl = sum(np.array([t.moments(am - lo, 1)[0][0] for t in ts]) for ts in tracks) / len(tracks)
+                y = dist_util.allgather_concat(yl, self.am.group) if world > 1 else yl
+                prob.augment_dataset(x, y)
+                for p in posts:
+                    p.append(x, y)
+                xs.append(x)
+        finally:
+            for ts in tracks:
+                for t in ts:
+                    t.close()
+            if cand is not None:
+                cand.close()
+        return np.stack(xs, axis=1)
 
 
 @dataclass

@@ -146,17 +146,19 @@ class HipGaussianProcess:
         return tot
 
     # ------------------------------------------------------------------ posterior
-    def model_posterior_slice(self, params: HipGPParams, data: ExperimentData, i: int) -> "HipGaussianProcessPosteriorSlice":
-        """model_posterior_slice (gaussian_process.jl:133-141)."""
+    def model_posterior_slice(self, params: HipGPParams, data: ExperimentData, i: int,
+                              reserve: int = 0) -> "HipGaussianProcessPosteriorSlice":
+        """model_posterior_slice (gaussian_process.jl:133-141).  reserve: room for later appends."""
         g = api.fit(data.X, data.Y[i], self.kernel, params.lengthscales[:, i], params.amplitudes[i], params.noise_std[i],
-                    self.mean_values(data.X, params, i), self.discrete, self.device)
+                    self.mean_values(data.X, params, i), self.discrete, self.device, reserve)
         return HipGaussianProcessPosteriorSlice(self, params, i, g)
 
-    def model_posterior(self, params, data: ExperimentData):
+    def model_posterior(self, params, data: ExperimentData, reserve: int = 0):
         """model_posterior (src/posterior.jl:8-19,38-41): a vector of params broadcasts (BI samples)."""
         if isinstance(params, (list, tuple)):
-            return [self.model_posterior(p, data) for p in params]
-        return HipGaussianProcessPosterior([self.model_posterior_slice(params, data, i) for i in range(data.Y.shape[0])])
+            return [self.model_posterior(p, data, reserve) for p in params]
+        return HipGaussianProcessPosterior([self.model_posterior_slice(params, data, i, reserve)
+                                            for i in range(data.Y.shape[0])])
 
 
 def _clip(var):

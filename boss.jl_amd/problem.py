@@ -171,15 +171,18 @@ def is_feasible(y, y_max) -> bool:
     return bool(np.all(np.asarray(y) <= np.asarray(y_max)))
 
 
-def best_so_far(fitness: LinFitness, Y, y_max):
-    """best_so_far (src/acquisitions/expected_improvement.jl:134-140): best RAW feasible observation."""
+def best_so_far(fitness, Y, y_max):
+    """best_so_far (src/acquisitions/expected_improvement.jl:134-140): best RAW feasible observation
+    (vectorised: this runs once per selection of a sequential batch, over all N observations)."""
     Y = np.asarray(Y, float)
     if Y.size == 0:
         return None
-    feas = [j for j in range(Y.shape[1]) if is_feasible(Y[:, j], y_max)]
-    if not feas:
+    feas = np.all(Y <= np.asarray(y_max, float)[:, None], axis=0)        # is_feasible (src/utils/utils.jl:33)
+    if not feas.any():
         return None
-    return max(fitness(Y[:, j]) for j in feas)
+    if isinstance(fitness, LinFitness):
+        return float(np.max(np.asarray(fitness.coefs, float) @ Y[:, feas]))
+    return max(fitness(Y[:, j]) for j in np.flatnonzero(feas))
 
 
 @dataclass

@@ -46,6 +46,7 @@ extern "C" {
 #define BOSS_FIT_NO_SYNC   1   /* enqueue only; logpdf_out is ignored, fetch later with boss_gp_sync */
 
 typedef struct boss_gp   boss_gp_t;    /* one output slice's posterior: resident X, y, L, z (GaussianProcessPosterior, gaussian_process.jl:127-131) */
+typedef struct boss_track boss_track_t; /* resident predictive state (V = L^-1 K*, mu, var) of one posterior at one candidate set */
 typedef struct boss_cand boss_cand_t;  /* a resident batch of candidate points (the `xs` of SamplingAM.sample, sampling.jl:43-46) */
 
 /* ---- library ---------------------------------------------------------------------- */
@@ -99,6 +100,9 @@ int boss_gp_set_y(boss_gp_t* gp, const double* y);
  * to rounding.  The handle must be fitted; device storage grows as needed. */
 int boss_gp_append(boss_gp_t* gp, int n, const double* X_new, const double* y_new, const double* mean_new,
                    double* logpdf_out);
+/* Reserve device storage for N_total observations (appends up to that size then need no
+ * re-allocation).  Leaves the handle unfitted: follow with boss_gp_update. */
+int boss_gp_reserve(boss_gp_t* gp, int N_total);
 void boss_gp_free(boss_gp_t* gp);
 
 /* introspection for parity tests: lower Cholesky factor L (N×N column-major, upper part zeroed)
@@ -196,6 +200,29 @@ int boss_acq_ei_moments(int device, int P, int S, int M, const double* mu, const
 int boss_acq_ei_grad(int P, boss_gp_t* const* gps, int M, const double* Xs, const double* mean_Xs,
                      const double* mean_grad, const double* fit_coefs, const double* y_max, int has_best,
                      double best, const unsigned char* valid_mask, double* acq_out, double* dacq_out);
+
+/* ---- tracked candidates -----------------------------------------------------------------------
+ * SequentialBatchAM (src/acquisition_maximizers/batch.jl:26-38) re-evaluates the acquisition on
+ * the whole candidate set after every speculative observation; with a FIXED candidate set (GridAM
+ * points, or a seeded sample) the forward-substitution result V = C.U' \ K* can stay resident and
+ * be EXTENDED by one row per appended observation (boss_gp_append) — an O(N M) update of mu and
+ * var instead of the O(N^2 M) re-solve:
+ *   boss_track_create   runs the prediction once and keeps V, mu, var (unclipped) on the device;
+ *                       mean_Xs: prior mean at the candidates (M values) or NULL;
+ *   boss_track_sync     brings the state up to the posterior's current N (no-op when in sync);
+ *   boss_track_moments  copies mu / var (unclipped, like mean_and_var before _clip_var) of the
+ *                       candidates [first, first+count) to the host (syncs first);
+ *   boss_acq_ei_tracks  = boss_acq_ei on tracked states (tracks[p + P*s]; syncs them first).
+ * A track is bound to the hyper-parameters of the boss_gp_update that preceded its creation:
+ * after another boss_gp_update every call returns BOSS_E_INVALID (create a new track).  The
+ * posterior handle must outlive its tracks. */
+int boss_track_create(boss_gp_t* gp, const boss_cand_t* cand, const double* mean_Xs, boss_track_t** out);
+void boss_track_free(boss_track_t* track);
+int boss_track_sync(boss_track_t* track);
+int boss_track_moments(boss_track_t* track, int first, int count, double* mu, double* var);
+int boss_acq_ei_tracks(int P, int S, boss_track_t* const* tracks, const double* fit_coefs, const double* y_max,
+                       int has_best, double best, const unsigned char* valid_mask,
+                       double* acq_out, long* argmax_out, double* max_out);
 
 /* ---- measurement helpers (bench.py / profiles) ------------------------------------------ */
 /* issue-rate microbenchmark of v_mfma_f64_16x16x4_f64: every SIMD of the device issues

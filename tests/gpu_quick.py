@@ -141,6 +141,46 @@ def grad_timing(d=8, N=4096, M=8192):
           f"|d dmu|={np.abs(dmu[:, :64]-dmu_o).max():.1e} |d dvar|={np.abs(dvar[:, :64]-dvar_o).max():.1e}", flush=True)
 
 
+def seqbatch_timing(d=8, N=4096, M=8192, nb=8):
+    """SequentialBatchAM's speculative loop at the BASELINE size: resident posterior + block Cholesky
+    appends, with and without tracked candidates, against the reference's pattern (re-factorise +
+    re-predict per selection)."""
+    import boss_jl_amd as B
+    X, y, Xs = problem(d, N, M)
+    prm = B.HipGPParams(np.full((d, 1), 0.5), [1.0], [0.05])
+    model = B.HipGaussianProcess([None], [None], [None])
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness([1.0])), model,
+                         B.ExperimentData(X, y[None, :]), None, prm)
+    res = {}
+    for name, am in (("tracked", B.HipBatchAM(points=Xs)), ("append only", B.HipBatchAM(points=Xs, shard="candidates"))):
+        sb = B.HipSequentialBatchAM(am, nb)
+        if name == "append only":
+            am.seed = None
+            pts = am.points
+            am.points = None
+            am.candidates = lambda problem, _p=pts: _p            # hides the fixed set from the tracker
+        sb.maximize_acquisition(prob)
+        sb1 = B.HipSequentialBatchAM(am, 1)
+        t = time.time()
+        sb1.maximize_acquisition(prob)
+        t1 = time.time() - t                                     # set-up (handles, factorisation, tracks) + 1 selection
+        t = time.time()
+        Xb, _ = sb.maximize_acquisition(prob)
+        res[name] = ((time.time() - t - t1) / (nb - 1), Xb, t1)
+    # reference pattern: fresh factorisation + prediction per selection
+    g = api.GP(X, y, "matern52")
+    cand = api.Candidates(Xs)
+    t = time.time()
+    for _ in range(nb):
+        g.update(np.full(d, 0.5), 1.0, 0.05)
+        api.acq_ei([[g]], cand, [1.0], None, float(y.max()), want_acq=False)
+    t_ref = (time.time() - t) / nb
+    same = np.array_equal(res["tracked"][1], res["append only"][1])
+    print(f"sequential batch N={N} M={M}: tracked {res['tracked'][0]*1e3:.2f} ms per further selection (set-up + first "
+          f"{res['tracked'][2]*1e3:.1f} ms), append only {res['append only'][0]*1e3:.2f} ms (set-up + first "
+          f"{res['append only'][2]*1e3:.1f} ms), re-factorise + re-predict {t_ref*1e3:.2f} ms;  same batch: {same}", flush=True)
+
+
 def batch_big(N=4096, d=8):
     """Batched posterior updates at the BASELINE size: S hyper-parameter sets on the same data."""
     X, y, _ = problem(d, N, 1)
@@ -207,6 +247,8 @@ if __name__ == "__main__":
         append_timing()
     if "batch" in stages:
         batch_cfg()
+    if "seqbatch" in stages:
+        seqbatch_timing()
     if "grad" in stages:
         grad_timing()
     if "batch_big" in stages:

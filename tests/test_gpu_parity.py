@@ -747,6 +747,43 @@ def test_gradient_maximizer_beats_its_starts_and_matches_a_dense_grid(api, O):
     assert val >= O.ei_acquisition([post], S0, [1.0], [np.inf], b).max() - 1e-12
 
 
+@pytest.mark.parametrize("N0,steps", [(100, [1, 1, 1]), (250, [3, 9, 1]), (500, [1] * 4)])
+def test_tracked_candidates_follow_appends(api, O, N0, steps):
+    """boss_track_*: after GP.append the resident moments are extended row by row and equal a fresh
+    prediction on the augmented data; the tracked acquisition equals boss_acq_ei."""
+    rng = np.random.default_rng(N0)
+    d, M = 3, 77
+    Ntot = N0 + sum(steps)
+    X = rng.uniform(0, 1, (d, Ntot))
+    y = np.sin(3 * X).sum(0) + 0.05 * rng.standard_normal(Ntot)
+    mean = 0.2 - 0.1 * X[1]
+    Xs = np.asfortranarray(rng.uniform(0, 1, (d, M)))
+    ms = 0.2 - 0.1 * Xs[1]
+    lam = np.array([0.4, 0.5, 0.6])
+    g = api.GP(X[:, :N0], y[:N0], "matern52")
+    g.update(lam, 1.1, 0.05, mean[:N0])
+    cand = api.Candidates(Xs)
+    tr = api.Track(g, cand, ms)
+    n_at = N0
+    for n in steps:
+        g.append(X[:, n_at:n_at + n], y[n_at:n_at + n], mean[n_at:n_at + n])
+        n_at += n
+        post = O.gp_fit(X[:, :n_at], y[:n_at], "matern52", lam, 1.1, 0.05, mean=mean[:n_at])
+        mu_o, var_o = O.gp_mean_and_var(post, Xs, ms, clip=False)
+        mu, var = tr.moments()
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), n_at
+        b = float(y[:n_at].max())
+        acq, am, mx = api.acq_ei_tracks([[tr]], [1.0], None, b)
+        acq2, am2, mx2 = api.acq_ei([[g]], cand, [1.0], None, b, None, ms[None, None])
+        assert np.allclose(acq, acq2, rtol=0, atol=1e-12) and am == am2
+    # a re-fit with new hyper-parameters invalidates the track
+    g.update(lam * 1.1, 1.1, 0.05, mean)
+    with pytest.raises(api.BossError):
+        tr.sync()
+    tr.close()
+    g.close()
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
