@@ -37,6 +37,7 @@ SIGNATURES = {
     "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
                               _c_ucp, C.POINTER(C.c_void_p), _c_dp]),
     "boss_gp_set_y": (C.c_int, [C.c_void_p, _c_dp]),
+    "boss_gp_loglike_grad": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
     "boss_gp_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "boss_gp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_gp_free": (None, [C.c_void_p]),
@@ -195,6 +196,14 @@ class GP:
     def set_y(self, y):
         y = _f64(np.asarray(y).reshape(-1), 1)
         _check(load_library().boss_gp_set_y(self._h, _dp(y)))
+
+    def loglike_grad(self):
+        """(logpdf, grad[d+2]) at the hyper-parameters of the last update: gradient w.r.t.
+        (lengthscale[d], amplitude, noise_std), analytic, on the device."""
+        out = C.c_double(0.0)
+        grad = np.zeros(self.d + 2)
+        _check(load_library().boss_gp_loglike_grad(self._h, C.byref(out), _dp(grad)))
+        return out.value, grad
 
     def reserve(self, N_total: int):
         """Reserve storage for N_total observations (later appends need no re-allocation); the handle

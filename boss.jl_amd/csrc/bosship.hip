@@ -60,7 +60,7 @@ struct Ctx {
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
-    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw;   // craw: raw candidates of one-shot calls
+    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC;   // lg*: log-likelihood gradient (LinvT, K⁻¹, partials)   // craw: raw candidates of one-shot calls
     void* pinned = nullptr;   // small host-pinned result area
     std::mutex mtx;
 };
@@ -101,6 +101,8 @@ static int get_ctx(int device, Ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)linvt_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)backsolve_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG64>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1426,6 +1428,65 @@ extern "C" int boss_acq_ei_moments(int device, int P, int S, int M, const double
     if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
     if (argmax_out) std::memcpy(argmax_out, &hres[1], sizeof(long));
     if (max_out) *max_out = hres[0];
+    return BOSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gradient of the log marginal likelihood w.r.t. (lengthscale[d], amplitude, noise_std) at the
+// hyper-parameters of the last boss_gp_update
+// ------------------------------------------------------------------------------------------
+extern "C" int boss_gp_loglike_grad(boss_gp_t* g, double* logpdf_out, double* grad_out) {
+    if (!g || !grad_out) return fail(BOSS_E_INVALID, "NULL argument");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    if (g->pending) {
+        int rc0 = gp_finish(g, nullptr);
+        if (rc0) return rc0;
+    }
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    const int d = g->d, N = g->N, Np = g->Np, ld = g->ld;
+    if (d > LLG_MAX_D) return fail(BOSS_E_INVALID, "x_dim too large for the likelihood-gradient kernel");
+    hipStream_t s = c->stream;
+    const int nt = Np / 64, ntiles = nt * (nt + 1) / 2, nv = d + 2, nch = 8;
+    int rc = ws_reserve(c->lgA, sizeof(double) * (size_t)ld * Np);
+    if (rc) return rc;
+    rc = ws_reserve(c->lgB, sizeof(double) * (size_t)ld * Np);
+    if (rc) return rc;
+    rc = ws_reserve(c->lgC, sizeof(double) * ((size_t)nch * Np + (size_t)ntiles * nv + nv));
+    if (rc) return rc;
+    double* LinvT = (double*)c->lgA.p;
+    double* Kinv = (double*)c->lgB.p;
+    double* apart = (double*)c->lgC.p;
+    double* parts = apart + (size_t)nch * Np;
+    double* sums = parts + (size_t)ntiles * nv;
+    dinv_join(g);
+    if (!g->have_dinv) {
+        dinv_launch(g, s);
+        g->have_dinv = true;
+    }
+    typedef PredG32 G;
+    hipLaunchKernelGGL(linvt_kernel<G>, dim3(Np / 32), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->A, ld, Np,
+                       (const double*)g->Dinv2, LinvT, ld);
+    hipLaunchKernelGGL(kinv_syrk_kernel<SyrkG>, dim3(g->nblk * (g->nblk + 1) / 2), dim3(256), 0, s, (const double*)LinvT, ld, Np, Kinv,
+                       ld);
+    hipLaunchKernelGGL(avec_partial_kernel, dim3(Np / 256, nch), dim3(256), 0, s, (const double*)LinvT, ld, Np, N,
+                       (const double*)g->A, ld, apart);
+    hipLaunchKernelGGL(llgrad_tile_kernel, dim3(ntiles), dim3(256), 0, s, (const double*)g->Xsc, d, N, Np, g->kernel, g->amp2,
+                       (const double*)Kinv, ld, (const double*)apart, nch, parts);
+    hipLaunchKernelGGL(llgrad_reduce_kernel, dim3(nv), dim3(256), 0, s, (const double*)parts, ntiles, nv, sums);
+    std::vector<double> h(nv);
+    HIPCHK(hipMemcpyAsync(h.data(), sums, sizeof(double) * nv, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    // host_par still holds the staged parameters of the last update: 1/(λ+1e-8), (α+1e-8)², (σ+1e-8)²
+    const double* invlam = g->host_par;
+    const double amp = std::sqrt(g->host_par[d]), sig2 = g->host_par[d + 1], sig = std::sqrt(sig2);
+    const double zz = g->host_res[1], trK = h[d], aa = h[d + 1];
+    for (int m = 0; m < d; ++m) grad_out[m] = -h[m] * invlam[m];                       // −S_m / λ_m
+    grad_out[d] = (zz - N - sig2 * (aa - trK)) / amp;
+    grad_out[d + 1] = sig * (aa - trK);
+    if (logpdf_out) *logpdf_out = -0.5 * (N * 1.8378770664093453 + g->host_res[0] + g->host_res[1]);
     return BOSS_OK;
 }
 

@@ -567,6 +567,200 @@ __global__ __launch_bounds__(256) void track_append_kernel(const double* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Gradient of the log marginal likelihood w.r.t. the hyper-parameters (second half):
+//     ∂ℓ/∂θ = ½ Σ_ij G_ij ∂K_ij/∂θ ,   G = a aᵀ − K⁻¹ ,  K⁻¹ = L⁻ᵀL⁻¹
+// (what ForwardDiff / Zygote deliver to OptimizationMAP, src/model_fitters/optimization.jl:146-164).
+//   linvt_kernel        LinvT[c + k·ldt] = (L⁻¹)[k, c]: forward substitution of the identity, 32 columns per
+//                       workgroup, the prediction kernel's 256-row-step machinery; the result matrix is also
+//                       the GEMM's B operand (ldb = ldt), and each tile starts at its own diagonal step
+//   kinv_syrk_kernel    K⁻¹ = LinvT·LinvTᵀ, 128×128 tiles, k runs from the tile's row block to the end
+//   avec_partial_kernel a = LinvT z (= L⁻ᵀ z), 8 k-chunks per 256 rows, summed in a fixed order
+//   llgrad_tile_kernel  per 64×64 lower tile: Σ G_ij α² h(r_ij) Δu²_ij,m (m < d), tr K⁻¹, ‖a‖²
+//   llgrad_reduce_kernel deterministic sum of the tile partials
+// ------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(G::NTHREADS) void linvt_kernel(const double* __restrict__ A, int ld, int Np,
+                                                            const double* __restrict__ Dinv2,
+                                                            double* __restrict__ LinvT, int ldt) {
+    static_assert(G::WC == 1 && G::BM == 2 * BLK && G::PM == 2 && G::WR == 4, "written for 256-row steps, 4 waves");
+    constexpr int RB = G::BM, BN = G::BN, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
+    extern __shared__ double lds[];
+    double* Rs = lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave, wc = 0;
+    const int c0 = blockIdx.x * BN;
+    double* V = LinvT + c0;                                  // V(row k, column c) at V[c + k·ldt]
+    const int nb = Np / RB, ib0 = c0 / RB;
+    for (int ib = ib0; ib < nb; ++ib) {
+        v4d acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        if (ib > ib0)
+            G::template run<1>(A + (size_t)ib * RB + (size_t)ib0 * RB * ld, ld, V + (size_t)ib0 * RB * ldt, ldt, (ib - ib0) * RB, acc);
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int row = G::row_of(wr, m, lane);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = G::col_of(wc, n, i, lane);
+                    Rs[row * LDR + col] = ((ib * RB + row == c0 + col) ? 1.0 : 0.0) - acc[m][n][i];
+                }
+        }
+        __syncthreads();
+        v4d acc2[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        G::run_Blds_tri(Dinv2 + (size_t)ib * RB * RB, RB, Rs, LDR, acc2);
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int row = ib * RB + G::tri_row_of(wr, m, lane);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) V[(size_t)row * ldt + G::col_of(wc, n, i, lane)] = acc2[m][n][i];
+        }
+        __syncthreads();
+    }
+}
+
+// needs SyrkG (potrf.hpp is included after this header by bosship.hip, so the kernel is templated on it)
+template <class SG>
+__global__ __launch_bounds__(256, 2) void kinv_syrk_kernel(const double* __restrict__ LinvT, int ldt, int Np,
+                                                           double* __restrict__ Kinv, int ldk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / SG::WC, wc = wave % SG::WC;
+    const int t = blockIdx.x;
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    const int J = t - I * (I + 1) / 2;
+    const int k0 = I * BLK;                                  // LinvT[i, k] = 0 for k < i
+    v4d acc[SG::TM][SG::TN];
+#pragma unroll
+    for (int m = 0; m < SG::TM; ++m)
+#pragma unroll
+        for (int n = 0; n < SG::TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    SG::template run<1>(LinvT + (size_t)I * BLK + (size_t)k0 * ldt, ldt, LinvT + (size_t)J * BLK + (size_t)k0 * ldt, ldt, Np - k0, acc);
+    double* C = Kinv + (size_t)I * BLK + (size_t)J * BLK * ldk;
+#pragma unroll
+    for (int m = 0; m < SG::TM; m += 2)
+#pragma unroll
+        for (int n = 0; n < SG::TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v2d c2 = {acc[m][n][i], acc[m + 1][n][i]};
+                *reinterpret_cast<v2d*>(C + SG::row_of(wr, m, lane) + (size_t)SG::col_of(wc, n, i, lane) * ldk) = c2;
+            }
+}
+
+// partial[chunk][i] = Σ_{k in chunk} LinvT[i, k] z_k   (z_k in row Np of the factor array; k < N)
+__global__ __launch_bounds__(256) void avec_partial_kernel(const double* __restrict__ LinvT, int ldt, int Np, int N,
+                                                           const double* __restrict__ A, int ld,
+                                                           double* __restrict__ partial) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nch = gridDim.y, ch = blockIdx.y;
+    const int kbeg0 = (blockIdx.x * 256 / PRED_RB) * PRED_RB;     // first written column of these rows
+    const int span = (Np - kbeg0 + nch - 1) / nch;
+    const int kb = kbeg0 + ch * span, ke = (kb + span < N) ? kb + span : N;
+    double s = 0.0;
+    for (int k = kb; k < ke; ++k) s = __builtin_fma(LinvT[(size_t)k * ldt + i], A[(size_t)k * ld + Np], s);
+    partial[(size_t)ch * Np + i] = s;
+}
+
+constexpr int LLG_MAX_D = 32;
+// out[tile][0..d-1] = Σ_{i>j in tile} G_ij α² h(r_ij) Δu²_ij,m ;  out[tile][d] = Σ_i K⁻¹_ii , out[tile][d+1] = Σ_i a_i²  (diagonal tiles)
+__global__ __launch_bounds__(256) void llgrad_tile_kernel(const double* __restrict__ Xsc, int d, int N, int Np, int kern,
+                                                          double amp2, const double* __restrict__ Kinv, int ldk,
+                                                          const double* __restrict__ apart, int nch,
+                                                          double* __restrict__ out) {
+    __shared__ double xj[LLG_MAX_D][64];
+    __shared__ double aj[64];
+    __shared__ double red[256];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const int r = tid & 63, cg = tid >> 6;
+    const int i = bi * 64 + r;
+    for (int idx = tid; idx < d * 64; idx += 256) xj[idx >> 6][idx & 63] = Xsc[(size_t)(idx >> 6) * Np + bj * 64 + (idx & 63)];
+    if (tid < 64) {
+        double s = 0.0;
+        for (int c = 0; c < nch; ++c) s += apart[(size_t)c * Np + bj * 64 + tid];
+        aj[tid] = s;
+    }
+    double ai = 0.0;
+    for (int c = 0; c < nch; ++c) ai += apart[(size_t)c * Np + i];
+    __syncthreads();
+    double S[LLG_MAX_D];
+#pragma unroll
+    for (int m = 0; m < LLG_MAX_D; ++m) S[m] = 0.0;
+    double tr = 0.0, aa = 0.0;
+    double xi[LLG_MAX_D];
+#pragma unroll
+    for (int m = 0; m < LLG_MAX_D; ++m) xi[m] = (m < d) ? Xsc[(size_t)m * Np + i] : 0.0;
+    for (int c = 0; c < 16; ++c) {
+        const int jl = cg * 16 + c, j = bj * 64 + jl;
+        if (i >= N || j >= N) continue;
+        if (i == j) {
+            tr += Kinv[(size_t)j * ldk + i];
+            aa += ai * ai;
+            continue;
+        }
+        if (i < j) continue;
+        double r2 = 0.0, du2[LLG_MAX_D];
+#pragma unroll
+        for (int m = 0; m < LLG_MAX_D; ++m) {
+            const double df = (m < d) ? xi[m] - xj[m][jl] : 0.0;
+            du2[m] = df * df;
+            r2 += du2[m];
+        }
+        const double g = ai * aj[jl] - Kinv[(size_t)j * ldk + i];
+        const double q = g * amp2 * kappa_prime_over_r_r2(kern, r2);
+#pragma unroll
+        for (int m = 0; m < LLG_MAX_D; ++m) S[m] = __builtin_fma(q, du2[m], S[m]);
+    }
+    // workgroup reduction of the d + 2 sums (one at a time; d is small)
+    for (int m = 0; m < d + 2; ++m) {
+        double v = (m < d) ? 0.0 : (m == d ? tr : aa);
+#pragma unroll
+        for (int mm = 0; mm < LLG_MAX_D; ++mm)
+            if (mm == m) v = S[mm];
+        if (m >= d) v = (m == d) ? tr : aa;
+        __syncthreads();
+        red[tid] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) out[(size_t)t * (d + 2) + m] = red[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void llgrad_reduce_kernel(const double* __restrict__ parts, int ntiles, int nv,
+                                                            double* __restrict__ out) {
+    __shared__ double red[256];
+    const int m = blockIdx.x;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) s += parts[(size_t)t * nv + m];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[m] = red[0];
+}
+
 // a5: full posterior covariance  Σ = K** − VᵀV + 1e-18·I  (mean_and_cov, gaussian_process.jl:180-184;
 // AbstractGPs cov(post(X*))) from the V slabs the prediction kernel left in its scratch
 // (V(n, j) = Vs[(j/BN * Np + n) * BN + j % BN]).  16×16 outputs per workgroup, n staged through LDS.

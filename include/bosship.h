@@ -105,6 +105,16 @@ int boss_gp_append(boss_gp_t* gp, int n, const double* X_new, const double* y_ne
 int boss_gp_reserve(boss_gp_t* gp, int N_total);
 void boss_gp_free(boss_gp_t* gp);
 
+/* Gradient of the log marginal likelihood w.r.t. the hyper-parameters.  Replaces: the
+ * derivative of `loglike` (data_loglike, gaussian_process.jl:250-280) that OptimizationMAP's
+ * optimiser obtains by automatic differentiation (src/model_fitters/optimization.jl:146-164).
+ * Evaluated at the hyper-parameters of the last boss_gp_update on this handle:
+ *   grad_out[0..d-1] = d logpdf / d lengthscale_m,  grad_out[d] = d/d amplitude,  grad_out[d+1] = d/d noise_std
+ *   (d logpdf/d theta = 1/2 tr((a a' - K^-1) dK/dtheta), K^-1 = L^-T L^-1 formed on the device);
+ *   logpdf_out (may be NULL) returns the value again.  The prior mean is treated as constant in theta.
+ * Costs about one acquisition pass (triangular inverse) + a K = N syrk. */
+int boss_gp_loglike_grad(boss_gp_t* gp, double* logpdf_out, double* grad_out);
+
 /* introspection for parity tests: lower Cholesky factor L (N×N column-major, upper part zeroed)
  * and z = L \ (y - m) (N). Either pointer may be NULL. */
 int boss_gp_get_factor(const boss_gp_t* gp, double* L_out, double* z_out);

@@ -234,6 +234,33 @@ def data_loglike(X, Y, kernel, lengthscales, amplitudes, noise_stds, means=None,
 # --------------------------------------------------------------------------------------
 # prediction   (gaussian_process.jl:143-194 -> AbstractGPs mean_and_var(post(X*)))
 # --------------------------------------------------------------------------------------
+def gp_data_loglike_grad(X, y, kernel, lengthscale, amplitude, noise_std, mean=None, discrete=None):
+    """logpdf(FiniteGP, y) (gp_data_loglike_slice, gaussian_process.jl:269-280) and its gradient w.r.t. the
+    INPUT hyper-parameters (λ_1..λ_d, α, σ) — what ForwardDiff / Zygote produce when OptimizationMAP
+    maximises the likelihood (src/model_fitters/optimization.jl:146-164).  With K = α²κ + σ²I (after the
+    +1e-8 offsets), a = K⁻¹(y−m), G = a aᵀ − K⁻¹:
+        ∂ℓ/∂θ = ½ Σ_ij G_ij ∂K_ij/∂θ ,
+        ∂K/∂λ_m = −α² h(r) Δ_m² / λ_m³ ,  ∂K/∂α = 2α κ ,  ∂K/∂σ = 2σ I .
+    Returns (logpdf, grad[d+2])."""
+    X = np.asarray(X, dtype=np.float64)
+    d, N = X.shape
+    post = gp_fit(X, y, kernel, lengthscale, amplitude, noise_std, mean=mean, discrete=discrete)
+    h = post.h
+    Xa = discrete_round(X, h.discrete)
+    r = scaled_distance(Xa, Xa, h.lengthscale)
+    amp2 = h.amplitude ** 2
+    Kinv = sla.cho_solve((post.L, True), np.eye(N), check_finite=False)
+    G = np.outer(post.a, post.a) - Kinv
+    Q = amp2 * kappa_prime_over_r(h.kernel, r)
+    grad = np.zeros(d + 2)
+    for m in range(d):
+        diff = Xa[m][:, None] - Xa[m][None, :]
+        grad[m] = 0.5 * np.sum(G * (-Q * diff * diff / h.lengthscale[m] ** 3))
+    grad[d] = 0.5 * np.sum(G * (2.0 * h.amplitude * kappa(h.kernel, r)))
+    grad[d + 1] = 0.5 * np.trace(G) * 2.0 * h.noise_std
+    return post.logpdf, grad
+
+
 def clip_var(var, threshold: float = MAX_NEG_VAR):
     """_clip_var (gaussian_process.jl:186-194): >=0 keep; [-thr,0) -> 0; < -thr -> DomainError."""
     v = np.asarray(var, dtype=np.float64)

@@ -181,6 +181,30 @@ def seqbatch_timing(d=8, N=4096, M=8192, nb=8):
           f"{res['append only'][2]*1e3:.1f} ms), re-factorise + re-predict {t_ref*1e3:.2f} ms;  same batch: {same}", flush=True)
 
 
+def llgrad_timing(d=8, N=4096):
+    """log-likelihood + its hyper-parameter gradient at the BASELINE size."""
+    X, y, _ = problem(d, N, 1)
+    lam = np.full(d, 0.5)
+    g = api.GP(X, y, "matern52")
+    g.update(lam, 1.0, 0.05)
+    g.loglike_grad()
+    t = time.time()
+    for i in range(5):
+        g.update(lam, 1.0, 0.05 + 1e-4 * i)
+        lp, grad = g.loglike_grad()
+    dt = (time.time() - t) / 5
+    t = time.time()
+    for i in range(5):
+        g.update(lam, 1.0, 0.05 + 1e-4 * i)
+    du = (time.time() - t) / 5
+    _, grad_o = O.gp_data_loglike_grad(X[:, :512], y[:512], "matern52", lam, 1.0, 0.05)
+    g2 = api.GP(X[:, :512], y[:512], "matern52")
+    g2.update(lam, 1.0, 0.05)
+    _, g512 = g2.loglike_grad()
+    print(f"loglike + gradient N={N}: {dt*1e3:.2f} ms per (update + gradient) vs update alone {du*1e3:.2f} ms;  "
+          f"rel err at N=512: {np.abs(g512-grad_o).max()/(1+np.abs(grad_o).max()):.1e}", flush=True)
+
+
 def batch_big(N=4096, d=8):
     """Batched posterior updates at the BASELINE size: S hyper-parameter sets on the same data."""
     X, y, _ = problem(d, N, 1)
@@ -247,6 +271,8 @@ if __name__ == "__main__":
         append_timing()
     if "batch" in stages:
         batch_cfg()
+    if "llgrad" in stages:
+        llgrad_timing()
     if "seqbatch" in stages:
         seqbatch_timing()
     if "grad" in stages:

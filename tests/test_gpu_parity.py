@@ -784,6 +784,32 @@ def test_tracked_candidates_follow_appends(api, O, N0, steps):
     g.close()
 
 
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+@pytest.mark.parametrize("d,N", [(1, 7), (3, 200), (8, 700), (17, 300)])
+def test_loglike_gradient(api, O, kernel, d, N):
+    """boss_gp_loglike_grad: ∂logpdf/∂(λ, α, σ) against the oracle's analytic restatement
+    (itself pinned to finite differences on the CPU)."""
+    rng = np.random.default_rng(13 * d + N)
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0) / np.sqrt(d) + 0.1 * rng.standard_normal(N)
+    mean = 0.1 + 0.2 * X[0]
+    lam = rng.uniform(0.4, 0.9, d) * np.sqrt(d)
+    amp, sig = 1.2, 0.1
+    g = api.GP(X, y, kernel)
+    lp = g.update(lam, amp, sig, mean)
+    lp2, grad = g.loglike_grad()
+    ll_o, grad_o = O.gp_data_loglike_grad(X, y, kernel, lam, amp, sig, mean=mean)
+    assert lp2 == lp and abs(lp - ll_o) <= 1e-10 * (1 + abs(ll_o))
+    tol = 1e-8 * (1.0 + np.abs(grad_o).max())
+    assert np.allclose(grad, grad_o, rtol=0, atol=tol), (grad, grad_o)
+    # still consistent after another update (the scratch matrices are per device, not per handle)
+    lp3 = g.update(lam * 1.2, amp * 0.9, sig * 1.5, mean)
+    _, grad3 = g.loglike_grad()
+    _, grad3_o = O.gp_data_loglike_grad(X, y, kernel, lam * 1.2, amp * 0.9, sig * 1.5, mean=mean)
+    assert np.allclose(grad3, grad3_o, rtol=0, atol=1e-8 * (1.0 + np.abs(grad3_o).max()))
+    g.close()
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch

@@ -147,3 +147,24 @@ def test_acquisition_gradient_restatement_against_finite_differences():
             fd = (O.ei_acquisition(posts, Xp, coefs, ym, bb, means_s=ms(Xp)) -
                   O.ei_acquisition(posts, Xm, coefs, ym, bb, means_s=ms(Xm))) / (2 * eps)
             assert np.allclose(dacq[k], fd, rtol=1e-5, atol=1e-8), (ym, bb, k)
+
+
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+def test_loglike_gradient_restatement_against_finite_differences(kernel):
+    rng = np.random.default_rng(3)
+    d, N = 3, 30
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0) + 0.1 * rng.standard_normal(N)
+    mean = 0.1 + 0.2 * X[0]
+    lam, amp, sig = np.array([0.4, 0.7, 0.5]), 1.3, 0.1
+    ll, g = O.gp_data_loglike_grad(X, y, kernel, lam, amp, sig, mean=mean)
+    assert abs(ll - O.gp_data_loglike_slice(X, y, kernel, lam, amp, sig, mean=mean)) <= 1e-12
+    th = np.concatenate([lam, [amp, sig]])
+    eps = 1e-6
+    for k in range(d + 2):
+        tp, tm = th.copy(), th.copy()
+        tp[k] += eps
+        tm[k] -= eps
+        fd = (O.gp_data_loglike_slice(X, y, kernel, tp[:d], tp[d], tp[d + 1], mean=mean) -
+              O.gp_data_loglike_slice(X, y, kernel, tm[:d], tm[d], tm[d + 1], mean=mean)) / (2 * eps)
+        assert abs(g[k] - fd) <= 1e-5 * (1 + abs(fd)), (k, g[k], fd)
