@@ -25,6 +25,9 @@ class Dirac:
     def logpdf(self, x):
         return 0.0 if x == self.value else -math.inf
 
+    def grad_logpdf(self, x):
+        return 0.0
+
 
 @dataclass
 class LogNormal:
@@ -39,6 +42,10 @@ class LogNormal:
             return -math.inf
         z = (math.log(x) - self.mu) / self.sigma
         return -math.log(x * self.sigma) - 0.5 * math.log(2 * math.pi) - 0.5 * z * z
+
+    def grad_logpdf(self, x):
+        """d logpdf / dx."""
+        return -(1.0 + (math.log(x) - self.mu) / self.sigma ** 2) / x
 
 
 @dataclass
@@ -59,6 +66,11 @@ class MvLogNormal:
         z = (np.log(x) - mu) / s
         return float(np.sum(-np.log(x * s) - 0.5 * math.log(2 * math.pi) - 0.5 * z * z))
 
+    def grad_logpdf(self, x):
+        x = np.asarray(x, float)
+        mu, s = np.asarray(self.mu, float), np.asarray(self.sigma, float)
+        return -(1.0 + (np.log(x) - mu) / s ** 2) / x
+
 
 @dataclass
 class MvDirac:
@@ -69,6 +81,9 @@ class MvDirac:
 
     def logpdf(self, x):
         return 0.0 if np.array_equal(np.asarray(x, float), np.asarray(self.values, float)) else -math.inf
+
+    def grad_logpdf(self, x):
+        return np.zeros(len(self.values))
 
 
 # ---------------------------------------------------------------- domain / data / fitness

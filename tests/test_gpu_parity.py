@@ -810,6 +810,41 @@ def test_loglike_gradient(api, O, kernel, d, N):
     g.close()
 
 
+def test_gradient_map_fitter_improves_on_its_starts(api, O):
+    """HipGradientMAP (OptimizationMAP semantics with device gradients): every start ends at a log-posterior
+    no lower than where it began, Dirac-prior parameters stay fixed, and the result beats plain sampling with
+    the same number of likelihood evaluations' worth of prior draws."""
+    import boss_jl_amd as B
+    rng = np.random.default_rng(6)
+    d, N, P = 2, 80, 2
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(6 * X[0]) + 0.3 * X[1], np.cos(4 * X[1])]) + 0.05 * rng.standard_normal((P, N))
+    model = B.HipGaussianProcess(lengthscale_priors=[B.MvLogNormal([-1., -1.], [1., 1.])] * P,
+                                 amplitude_priors=[B.LogNormal(0., 1.)] * P,
+                                 noise_std_priors=[B.LogNormal(-2., 1.), B.Dirac(0.05)])
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness([1., 0.])), model,
+                         B.ExperimentData(X, Y))
+    fit = B.HipGradientMAP(multistart=4, iters=25, seed=3)
+    allr = fit.estimate_parameters(prob, return_all=True)
+    assert len(allr) == 4
+    sampler, prior_ll = model.params_sampler(), model.params_loglike()
+    srng = np.random.default_rng(3)
+    starts = [sampler(srng) for _ in range(4)]
+
+    def logpost(p):
+        return O.data_loglike(X, Y, "matern52", p.lengthscales, p.amplitudes, p.noise_std) + prior_ll(p)
+
+    for r, s0 in zip(allr, starts):
+        assert r.params.noise_std[1] == 0.05                                  # Dirac parameter untouched
+        lp = logpost(r.params)
+        assert abs(lp - r.loglike) <= 1e-8 * (1 + abs(lp))                    # the reported value is the oracle's value
+        assert r.loglike >= logpost(s0) - 1e-9
+    best = fit.estimate_parameters(prob)
+    assert best.loglike == max(r.loglike for r in allr)
+    sampled = B.HipBatchedMAP(samples=200, seed=3).estimate_parameters(prob)
+    assert best.loglike >= sampled.loglike - 1e-6
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
