@@ -179,4 +179,13 @@ function acq_value_and_grad(problem::BOSS.BossProblem, post, X::AbstractMatrix{<
         something(b, 0.0), ei.cons_safe ? mask : C_NULL, acq, dacq))
     return acq, dacq          # feed an Optimization.jl OptimizationFunction(f; grad = ...) per start, or batch the starts
 end
+# ---------------------------------------------------------------- likelihood gradient for OptimizationMAP-style fitters
+# (value, gradient) of the data log-likelihood of output slice i at hyper-parameters p, on resident data:
+function loglike_and_grad!(h::Ptr{Cvoid}, λ::Vector{Float64}, α::Float64, σ::Float64, mean_X)
+    lp = Ref{Cdouble}(); g = Vector{Float64}(undef, length(λ) + 2)
+    check(ccall((:boss_gp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Ref{Cdouble}),
+          h, λ, α, σ, mean_X, 0, lp))
+    check(ccall((:boss_gp_loglike_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, C_NULL, g))
+    return lp[], g            # g = [∂/∂λ_1 … ∂/∂λ_d, ∂/∂α, ∂/∂σ]; add the priors' gradients and chain through the bijector
+end
 end # module
