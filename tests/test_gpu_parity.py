@@ -333,6 +333,61 @@ def test_full_size_properties(api, O):
     g.close()
 
 
+def test_full_size_next_rows(api, O):
+    """BASELINE size (N=4096, d=8) for the rows built beyond the headline path: appended observations,
+    tracked candidates, moment / acquisition / likelihood gradients — against fresh device results,
+    oracle slices and central finite differences of the device's own values (size-independent checks)."""
+    d, N, M = 8, 4096, 2048
+    X, y, Xs = make(d, N + 5, M, seed=1)
+    lam = np.full(d, 0.5)
+    g = api.GP(X[:, :N], y[:N], "matern52")
+    g.reserve(N + 5)
+    lp = g.update(lam, 1.0, 0.05)
+    cand = api.Candidates(Xs)
+    tr = api.Track(g, cand)
+    # (1) likelihood gradient == central differences of the device's own log-likelihood
+    _, grad = g.loglike_grad()
+    eps = 1e-5
+    for k, (dl, da, ds) in enumerate([(np.eye(d)[0], 0, 0), (np.eye(d)[d - 1], 0, 0), (np.zeros(d), 1, 0), (np.zeros(d), 0, 1)]):
+        fp = g.update(lam + eps * dl, 1.0 + eps * da, 0.05 + eps * ds)
+        fm = g.update(lam - eps * dl, 1.0 - eps * da, 0.05 - eps * ds)
+        want = (fp - fm) / (2 * eps)
+        got = grad[[0, d - 1, d, d + 1][k]]
+        assert abs(got - want) <= 2e-5 * (1 + abs(want)), (k, got, want)
+    g.update(lam, 1.0, 0.05)
+    tr.close()
+    tr = api.Track(g, cand)
+    # (2) five appended observations: bit-identical to a fresh factorisation; the tracked moments follow
+    for i in range(5):
+        lpa = g.append(X[:, N + i], y[N + i])
+    g2 = api.GP(X, y, "matern52")
+    lp2 = g2.update(lam, 1.0, 0.05)
+    assert lpa == lp2
+    mu_t, var_t = tr.moments()
+    mu_f, var_f = g2.predict(Xs)
+    assert np.allclose(mu_t, mu_f, rtol=0, atol=1e-10) and np.allclose(np.maximum(var_t, 0), var_f, rtol=0, atol=1e-10)
+    # (3) moment gradients: oracle slice + central differences of the device prediction
+    mu, var, dmu, dvar = g2.predict_grad(Xs)
+    post = O.gp_fit(X, y, "matern52", lam, 1.0, 0.05)
+    _, _, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs[:, :64])
+    assert np.allclose(dmu[:, :64], dmu_o, rtol=0, atol=1e-9 * (1 + np.abs(dmu_o).max()))
+    assert np.allclose(dvar[:, :64], dvar_o, rtol=0, atol=1e-9 * (1 + np.abs(dvar_o).max()))
+    e = np.zeros((d, 1))
+    e[3] = 1e-6
+    mp, vp = g2.predict(Xs + e)
+    mm, vm = g2.predict(Xs - e)
+    assert np.allclose(dmu[3], (mp - mm) / 2e-6, rtol=0, atol=1e-5 * (1 + np.abs(dmu[3]).max()))
+    assert np.allclose(dvar[3], (vp - vm) / 2e-6, rtol=0, atol=1e-5 * (1 + np.abs(dvar[3]).max()))
+    # (4) acquisition gradient == chain rule through the oracle's EI formulas applied to the device moments
+    b = float(y.max()) - 0.2
+    acq, dacq = api.acq_ei_grad([g2], Xs, [1.0], None, b)
+    ei, dei = O.expected_improvement_lin_grad([1.0], mu[None], var[None], dmu[None], dvar[None], b)
+    assert np.allclose(acq, ei, rtol=0, atol=1e-12) and np.allclose(dacq, dei, rtol=0, atol=1e-10 * (1 + np.abs(dei).max()))
+    tr.close()
+    g.close()
+    g2.close()
+
+
 def test_posterior_covariance(api, O):
     """a5: mean_and_cov(post, X) (gaussian_process.jl:180-184) from the device-resident factor."""
     X, y, Xs = make(3, 200, 37, seed=13)
