@@ -60,7 +60,7 @@ struct Ctx {
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
-    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC;   // lg*: log-likelihood gradient (LinvT, K⁻¹, partials)   // craw: raw candidates of one-shot calls
+    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC, few;   // lg*: log-likelihood gradient (LinvT, K⁻¹, partials)   // craw: raw candidates of one-shot calls
     void* pinned = nullptr;   // small host-pinned result area
     std::mutex mtx;
 };
@@ -101,6 +101,8 @@ static int get_ctx(int device, Ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)few_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)linvt_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)backsolve_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -989,6 +991,36 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     hipLaunchKernelGGL(scale_cand_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, cd->Craw, Csc, g->invlam,
                        g->discrete_dev, g->d, Mp);
     const int dbg = getenv("BOSS_DBG") ? atoi(getenv("BOSS_DBG")) : 0;
+    static const bool no_few = getenv("BOSS_NO_FEW") && atoi(getenv("BOSS_NO_FEW"));
+    static const int few_max_tiles = getenv("BOSS_FEW_MAX_TILES") ? atoi(getenv("BOSS_FEW_MAX_TILES")) : 128;
+    const int ftiles = (cd->M + 31) / 32;
+    if (ftiles <= few_max_tiles && g->Np >= 4 * PRED_RB && g->d <= 64 && !no_few && (BN == 32 || for_grad)) {
+        // few candidates (the fused kernel would occupy `ftiles` of 256 CUs for its whole latency):
+        // right-looking substitution, every 256-row step spread over the chip
+        typedef PredG32 G;
+        typedef GemmDirect<4, 1, 2, 2, 8> GU;                // 128×32 update tiles
+        ProfScope ps(c, "predict");
+        const int nb = g->Np / PRED_RB;
+        rc = ws_reserve(c->few, sizeof(double) * (size_t)ftiles * ((size_t)g->Np * 32 + 64));
+        if (rc) return rc;
+        double* R = (double*)c->few.p;                       // residuals [tile][Np][32], start as K*
+        double* ssmz = R + (size_t)ftiles * g->Np * 32;
+        double* V = (double*)c->vscratch.p;
+        (void)hipMemsetAsync(ssmz, 0, sizeof(double) * 64 * ftiles, s);
+        hipLaunchKernelGGL(kstar_rows_kernel, dim3(g->Np / 256, ftiles), dim3(256), sizeof(double) * g->d * 32, s,
+                           (const double*)g->Xsc, g->Np, g->N, (const double*)Csc, g->d, Mp, g->kernel, g->amp2, R);
+        for (int ib = 0; ib < nb; ++ib) {
+            hipLaunchKernelGGL(few_finish_kernel<G>, dim3(ftiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->A,
+                               g->ld, g->Np, ib, (const double*)R, (const double*)g->Dinv2, V, ssmz, ib == nb - 1 ? 1 : 0,
+                               mean_s_dev, cd->M, g->amp2, mu, var);
+            const int nupd = (nb - 1 - ib) * (PRED_RB / BLK);
+            if (nupd > 0)
+                hipLaunchKernelGGL(few_update_kernel<GU>, dim3(nupd, ftiles), dim3(GU::NTHREADS), 0, s, (const double*)g->A, g->ld,
+                                   g->Np, ib, (const double*)V, R);
+        }
+        HIPCHK(hipGetLastError());
+        return BOSS_OK;
+    }
     {
         ProfScope ps(c, "predict");
         if (BN == 32) {

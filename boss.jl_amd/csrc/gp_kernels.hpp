@@ -244,6 +244,155 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Few candidates (M <= 32: the reference's own call pattern is ONE candidate per call,
+// expected_improvement.jl:75,79).  The fused kernel above gives one workgroup per 32 candidates, i.e.
+// ONE busy CU and ≈2.1 ms of latency at N=4096.  Here the substitution runs right-looking in 256-row
+// steps spread over the chip, on a residual array R (Np × 32) that starts as K*:
+//   kstar_rows_kernel   R = K* (all rows × 32 candidates), one row per thread
+//   few_finish_kernel   V_i = Dinv2_i R_i, Σv², v·z (and μ, σ² at the last step)           — one workgroup
+//   few_update_kernel   R_j −= L[j, i] V_i for every later row block j                       — one workgroup per 128 rows
+// Two short launches per step instead of one long-running workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kstar_rows_kernel(const double* __restrict__ Xsc, int Np, int N,
+                                                         const double* __restrict__ Csc, int d, int Mp, int kern,
+                                                         double amp2, double* __restrict__ kst) {
+    extern __shared__ double cs[];                           // [d][32]
+    const int c0 = blockIdx.y * 32;                          // candidate tile
+    kst += (size_t)blockIdx.y * Np * 32;
+    for (int idx = threadIdx.x; idx < d * 32; idx += 256) cs[idx] = Csc[(size_t)(idx >> 5) * Mp + c0 + (idx & 31)];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double r2[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) r2[c] = 0.0;
+    for (int kd = 0; kd < d; ++kd) {
+        const double xr = Xsc[(size_t)kd * Np + row];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const double df = xr - cs[kd * 32 + c];
+            r2[c] = __builtin_fma(df, df, r2[c]);
+        }
+    }
+    const bool live = row < N;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) kst[(size_t)row * 32 + c] = live ? amp2 * kappa_r2(kern, r2[c]) : 0.0;
+}
+
+// GU = GemmDirect<4,1,2,2,D>: 128 rows × 32 candidates per workgroup, K = 256
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void few_update_kernel(const double* __restrict__ A, int ld, int Np, int ib,
+                                                                  const double* __restrict__ V, double* __restrict__ R) {
+    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
+    constexpr int TM = GU::TM, TN = GU::TN;
+    V += (size_t)blockIdx.y * Np * 32;                       // candidate tile
+    R += (size_t)blockIdx.y * Np * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = (ib + 1) * PRED_RB + blockIdx.x * BLK;    // first row of this workgroup's block
+    double* Rb = R + (size_t)r0 * 32;
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][n][i] = Rb[row * 32 + GU::col_of(0, n, i, lane)];
+    }
+    GU::template run<-1>(A + (size_t)r0 + (size_t)ib * PRED_RB * ld, ld, V + (size_t)ib * PRED_RB * 32, 32, PRED_RB, acc);
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Rb[row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* __restrict__ A, int ld, int Np, int ib,
+                                                                 const double* __restrict__ R,
+                                                                 const double* __restrict__ Dinv2, double* __restrict__ V,
+                                                                 double* __restrict__ ssmz, int last,
+                                                                 const double* __restrict__ mean_s, int M, double amp2,
+                                                                 double* __restrict__ mu_out, double* __restrict__ var_out) {
+    constexpr int RB = G::BM, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR, BN = 32;
+    extern __shared__ double lds[];
+    double* Rs = lds;
+    double* red = Rs + RB * LDR;                             // [2][WR][BN]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.x * BN;                          // candidate tile
+    R += (size_t)blockIdx.x * Np * 32;
+    V += (size_t)blockIdx.x * Np * 32;
+    ssmz += (size_t)blockIdx.x * 64;
+    const double* Rb = R + (size_t)ib * RB * 32;
+#pragma unroll 8
+    for (int q = 0; q < RB * 32 / 256; ++q) {                // coalesced copy of the step's residual rows into LDS
+        const int e = tid + 256 * q;
+        Rs[(e >> 5) * LDR + (e & 31)] = Rb[e];
+    }
+    __syncthreads();
+    v4d acc2[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    G::run_Blds_tri(Dinv2 + (size_t)ib * RB * RB, RB, Rs, LDR, acc2);
+    double ps[TN][4], pz[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ps[n][i] = pz[n][i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = ib * RB + G::tri_row_of(wave, m, lane);
+        const double zr = A[(size_t)row * ld + Np];
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double v = acc2[m][n][i];
+                V[(size_t)row * BN + G::col_of(0, n, i, lane)] = v;
+                ps[n][i] = __builtin_fma(v, v, ps[n][i]);
+                pz[n][i] = __builtin_fma(v, zr, pz[n][i]);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double s = ps[n][i], z = pz[n][i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                s += __shfl_xor(s, off);
+                z += __shfl_xor(z, off);
+            }
+            if ((lane & 15) == 0) {
+                const int col = G::col_of(0, n, i, lane);
+                red[wave * BN + col] = s;
+                red[G::WR * BN + wave * BN + col] = z;
+            }
+        }
+    __syncthreads();
+    if (tid < BN) {
+        double s = ssmz[tid], z = ssmz[BN + tid];
+#pragma unroll
+        for (int w = 0; w < G::WR; ++w) {
+            s += red[w * BN + tid];
+            z += red[G::WR * BN + w * BN + tid];
+        }
+        ssmz[tid] = s;
+        ssmz[BN + tid] = z;
+        if (last && c0 + tid < M) {
+            mu_out[c0 + tid] = (mean_s ? mean_s[c0 + tid] : 0.0) + z;
+            var_out[c0 + tid] = amp2 - s + PREDICT_JITTER;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 256×256 diagonal-block inverses from the 128×128 ones (prediction with 256-row steps halves the
 // V-slab re-reads and the number of dependent steps per candidate tile):
 //     inv [ A 0 ; B C ] = [ A⁻¹ 0 ; −C⁻¹ B A⁻¹  C⁻¹ ]

@@ -205,6 +205,21 @@ def llgrad_timing(d=8, N=4096):
           f"rel err at N=512: {np.abs(g512-grad_o).max()/(1+np.abs(grad_o).max()):.1e}", flush=True)
 
 
+def few_timing(d=8, N=4096):
+    """The reference's call pattern: one candidate per call."""
+    X, y, Xs = problem(d, N, 64)
+    g = api.GP(X, y, "matern52")
+    g.update(np.full(d, 0.5), 1.0, 0.05)
+    X, y, Xs = problem(d, N, 8300)
+    for M in (1, 32, 224, 1024, 2048, 4096, 8192):
+        g.predict(Xs[:, :M])
+        t = time.time()
+        for i in range(20):
+            g.predict(Xs[:, i:i + M])
+        dt = (time.time() - t) / 20
+        print(f"predict M={M} N={N}: {dt*1e3:.3f} ms per call ({M/dt:.0f} evals/s in the reference's call pattern)", flush=True)
+
+
 def batch_big(N=4096, d=8):
     """Batched posterior updates at the BASELINE size: S hyper-parameter sets on the same data."""
     X, y, _ = problem(d, N, 1)
@@ -271,6 +286,8 @@ if __name__ == "__main__":
         append_timing()
     if "batch" in stages:
         batch_cfg()
+    if "few" in stages:
+        few_timing()
     if "llgrad" in stages:
         llgrad_timing()
     if "seqbatch" in stages:

@@ -900,6 +900,38 @@ def test_gradient_map_fitter_improves_on_its_starts(api, O):
     assert best.loglike >= sampled.loglike - 1e-6
 
 
+@pytest.mark.parametrize("N,M", [(1024, 1), (1100, 5), (2048, 32), (4096, 1)])
+def test_few_candidates_path(api, O, N, M):
+    """M <= 32 at N >= 1024 takes the chip-wide step-by-step path (the reference evaluates ONE candidate
+    per call): moments, covariance and gradients agree with the oracle like the fused kernel's."""
+    rng = np.random.default_rng(N + M)
+    d = 4
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0) / 2 + 0.05 * rng.standard_normal(N)
+    mean = 0.2 - 0.1 * X[1]
+    Xs = rng.uniform(0, 1, (d, M))
+    ms = 0.2 - 0.1 * Xs[1]
+    lam = np.array([0.4, 0.5, 0.6, 0.7])
+    g = api.GP(X, y, "matern52")
+    g.update(lam, 1.1, 0.05, mean)
+    post = O.gp_fit(X, y, "matern52", lam, 1.1, 0.05, mean=mean)
+    mu, var = g.predict(Xs, ms)
+    mu_o, var_o = O.gp_mean_and_var(post, Xs, ms)
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+    if M == 1:                                               # the vector form of the plugin API
+        import boss_jl_amd as B
+        muv, varv = g.predict(Xs[:, 0], ms)
+        assert muv.shape == (1,) and abs(muv[0] - mu_o[0]) <= 1e-9
+    _, cov = g.predict_cov(Xs, ms)
+    _, cov_o = O.gp_mean_and_cov(post, Xs, ms)
+    assert np.allclose(cov, cov_o, rtol=0, atol=1e-9)
+    _, _, dmu, dvar = g.predict_grad(Xs, ms)
+    _, _, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs, ms)
+    assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8 * (1 + np.abs(dmu_o).max()))
+    assert np.allclose(dvar, dvar_o, rtol=0, atol=1e-8 * (1 + np.abs(dvar_o).max()))
+    g.close()
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
