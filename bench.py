@@ -241,7 +241,13 @@ def main():
             gp.update(lam, 1.0, 0.05 + 1e-4 * i)
             gp.loglike_grad()
         t_llg = (time.perf_counter() - t0) / 3
-        extras = {"loglike_with_hyperparameter_gradient_per_sec": 1.0 / t_llg, "ms_update_plus_loglike_grad": t_llg * 1e3,
+        gp.predict(Xs[:, :1])
+        t0 = time.perf_counter()
+        for i in range(20):
+            gp.predict(Xs[:, i:i + 1])
+        t_one = (time.perf_counter() - t0) / 20
+        extras = {"single_candidate_predicts_per_sec": 1.0 / t_one,
+                  "loglike_with_hyperparameter_gradient_per_sec": 1.0 / t_llg, "ms_update_plus_loglike_grad": t_llg * 1e3,
                   "block_cholesky_append_ms": t_app * 1e3,
                   "append_vs_refactorisation": (t_upd / args.steps) / t_app,
                   "posterior_gradient_evals_per_sec": M_CAND / t_grad, "ms_gradient_batch": t_grad * 1e3}

@@ -101,6 +101,8 @@ static int get_ctx(int device, Ctx** out) {
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)few_back_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)few_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)linvt_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1133,11 +1135,40 @@ static int grad_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_de
     typedef PredG32 G;
     const int tiles = (M + 31) / 32;
     double* slabs = (double*)c->vscratch.p;
-    hipLaunchKernelGGL(backsolve_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->LT, g->ld,
-                       Np, (const double*)g->DT2, slabs);
-    hipLaunchKernelGGL(grad_accum_kernel, dim3(tiles), dim3(256), glds, s, (const double*)slabs, (const double*)g->avec, Np, g->N,
-                       (const double*)g->Xsc, (const double*)c->csc.p, d, cd->Mp, M, g->kernel, g->amp2, (const double*)g->invlam,
-                       (const unsigned char*)g->discrete_dev, mean_grad_dev, dmu, dvar);
+    static const bool no_few = getenv("BOSS_NO_FEW") && atoi(getenv("BOSS_NO_FEW"));
+    static const int few_max_tiles = getenv("BOSS_FEW_MAX_TILES") ? atoi(getenv("BOSS_FEW_MAX_TILES")) : 128;
+    if (tiles <= few_max_tiles && Np >= 4 * PRED_RB && !no_few) {
+        // few candidates: the adjoint substitution step by step across the chip (see few_back_* kernels)
+        typedef GemmDirect<4, 1, 2, 2, 8> GU;
+        for (int ib = Np / PRED_RB - 1; ib >= 0; --ib) {
+            hipLaunchKernelGGL(few_back_finish_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s,
+                               (const double*)g->DT2, Np, ib, slabs);
+            if (ib > 0)
+                hipLaunchKernelGGL(few_back_update_kernel<GU>, dim3(ib * (PRED_RB / BLK), tiles), dim3(GU::NTHREADS), 0, s,
+                                   (const double*)g->LT, g->ld, Np, ib, slabs);
+        }
+    } else {
+        hipLaunchKernelGGL(backsolve_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->LT,
+                           g->ld, Np, (const double*)g->DT2, slabs);
+    }
+    // few tiles: split the rows of every tile over several workgroups (one workgroup per tile would walk all N rows alone)
+    int rsplit = 1;
+    if (d <= GRAD_MAX_D && tiles < 128) {
+        rsplit = std::min(32, std::max(1, 512 / tiles));
+        rsplit = std::min(rsplit, (g->N + GRAD_CHUNK - 1) / GRAD_CHUNK);
+    }
+    double* part = nullptr;
+    if (rsplit > 1) {
+        rc = ws_reserve(c->few, sizeof(double) * (size_t)tiles * std::max((size_t)Np * 32 + 64, (size_t)rsplit * 2 * (GRAD_MAX_D + 1) * 32));
+        if (rc) return rc;
+        part = (double*)c->few.p;                          // the forward pass's residuals are dead by now
+    }
+    hipLaunchKernelGGL(grad_accum_kernel, dim3(tiles, rsplit), dim3(256), glds, s, (const double*)slabs, (const double*)g->avec, Np,
+                       g->N, (const double*)g->Xsc, (const double*)c->csc.p, d, cd->Mp, M, g->kernel, g->amp2,
+                       (const double*)g->invlam, (const unsigned char*)g->discrete_dev, mean_grad_dev, dmu, dvar, part);
+    if (rsplit > 1)
+        hipLaunchKernelGGL(grad_finalize_kernel, dim3(tiles), dim3(32), 0, s, (const double*)part, rsplit, (const double*)c->csc.p, d,
+                           cd->Mp, M, (const double*)g->invlam, (const unsigned char*)g->discrete_dev, mean_grad_dev, dmu, dvar);
     HIPCHK(hipGetLastError());
     return BOSS_OK;
 }

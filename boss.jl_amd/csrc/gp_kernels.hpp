@@ -553,6 +553,72 @@ __global__ __launch_bounds__(G::NTHREADS) void backsolve_kernel(const double* __
     }
 }
 
+// Few candidates: the adjoint substitution W = L⁻ᵀV right-looking, from the LAST 256-row step to the first, in
+// place on the slabs (the unfinished rows hold the running residual):
+//   few_back_finish_kernel   W_i = Dinv2ᵀ_i R_i                                   — one workgroup per tile
+//   few_back_update_kernel   R_j −= Lᵀ[j, i] W_i for every EARLIER row block j    — one workgroup per 128 rows per tile
+template <class G>
+__global__ __launch_bounds__(G::NTHREADS) void few_back_finish_kernel(const double* __restrict__ DT2, int Np, int ib,
+                                                                      double* __restrict__ Vslabs) {
+    constexpr int RB = G::BM, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR, BN = 32;
+    extern __shared__ double lds[];
+    double* Rs = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* V = Vslabs + (size_t)blockIdx.x * Np * BN + (size_t)ib * RB * BN;
+#pragma unroll 8
+    for (int q = 0; q < RB * 32 / 256; ++q) {
+        const int e = tid + 256 * q;
+        Rs[(e >> 5) * LDR + (e & 31)] = V[e];
+    }
+    __syncthreads();
+    v4d acc2[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int kk0 = (TM * 16) * wave;                      // upper triangular: rows of wave w need k >= 64 w
+    G::run_Blds(DT2 + (size_t)ib * RB * RB + (size_t)kk0 * RB, RB, Rs + (size_t)kk0 * LDR, LDR, RB - kk0, acc2);
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = G::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) V[(size_t)row * BN + G::col_of(0, n, i, lane)] = acc2[m][n][i];
+    }
+}
+
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void few_back_update_kernel(const double* __restrict__ LT, int ldt, int Np, int ib,
+                                                                       double* __restrict__ Vslabs) {
+    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
+    constexpr int TM = GU::TM, TN = GU::TN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* V = Vslabs + (size_t)blockIdx.y * Np * 32;
+    const int r0 = blockIdx.x * BLK;                         // rows before step ib
+    double* Rb = V + (size_t)r0 * 32;
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][n][i] = Rb[row * 32 + GU::col_of(0, n, i, lane)];
+    }
+    GU::template run<-1>(LT + (size_t)r0 + (size_t)ib * PRED_RB * ldt, ldt, V + (size_t)ib * PRED_RB * 32, 32, PRED_RB, acc);
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Rb[row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
+    }
+}
+
 // ∇μ, ∇σ² from the W slabs:  with q_i = α² h(r_i),
 //     ∇μ_m  = ∇m_m + (u*_m Σ_i a_i q_i − Σ_i a_i q_i u_i,m) / λ_m ,   ∇σ²_m = −2 (u*_m Σ_i w_i q_i − Σ_i w_i q_i u_i,m) / λ_m
 // (u = x ⊘ λ).  One workgroup per 32-candidate slab: lanes run along the candidates, 8 row subsets;
@@ -566,7 +632,10 @@ __global__ __launch_bounds__(256) void grad_accum_kernel(const double* __restric
                                                          double amp2, const double* __restrict__ invlam,
                                                          const unsigned char* __restrict__ discrete,
                                                          const double* __restrict__ mean_grad,
-                                                         double* __restrict__ dmu, double* __restrict__ dvar) {
+                                                         double* __restrict__ dmu, double* __restrict__ dvar,
+                                                         double* __restrict__ part) {
+    // gridDim.y > 1 (few tiles, d <= 16): the rows are split over gridDim.y workgroups per tile, each writes its
+    // sums to part[(tile·gridDim.y + y)][2(GRAD_MAX_D+1)][32]; grad_finalize_kernel adds them in a fixed order
     constexpr int BN = 32;
     extern __shared__ double glds[];
     double* xs = glds;                                       // [d][GRAD_CHUNK] scaled coordinates of the chunk's rows
@@ -580,7 +649,11 @@ __global__ __launch_bounds__(256) void grad_accum_kernel(const double* __restric
         double S1 = 0.0, S2 = 0.0, T1[GRAD_MAX_D], T2[GRAD_MAX_D];
 #pragma unroll
         for (int m = 0; m < GRAD_MAX_D; ++m) T1[m] = T2[m] = 0.0;
-        for (int r0 = 0; r0 < N; r0 += GRAD_CHUNK) {
+        const int nchunk = (N + GRAD_CHUNK - 1) / GRAD_CHUNK;
+        const int cpb = (nchunk + gridDim.y - 1) / gridDim.y;
+        const int rbeg = blockIdx.y * cpb * GRAD_CHUNK;
+        const int rend = (rbeg + cpb * GRAD_CHUNK < N) ? rbeg + cpb * GRAD_CHUNK : N;
+        for (int r0 = rbeg; r0 < rend; r0 += GRAD_CHUNK) {
             __syncthreads();
             for (int idx = tid; idx < d * GRAD_CHUNK; idx += 256) {
                 const int m = idx / GRAD_CHUNK, rr = idx - m * GRAD_CHUNK;
@@ -623,6 +696,16 @@ __global__ __launch_bounds__(256) void grad_accum_kernel(const double* __restric
             rd[(3 + 2 * m) * BN + c] = T2[m];
         }
         __syncthreads();
+        if (gridDim.y > 1) {
+            // this workgroup's sums (over its 8 row subsets) go to global; the finalize kernel finishes
+            double* pw = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (2 * (GRAD_MAX_D + 1)) * BN;
+            for (int slot = rs; slot < 2 * (GRAD_MAX_D + 1); slot += 8) {
+                double v = 0.0;
+                for (int k = 0; k < 8; ++k) v += red[((size_t)k * (2 * (GRAD_MAX_D + 1)) + slot) * BN + c];
+                pw[slot * BN + c] = v;
+            }
+            return;
+        }
         if (rs == 0 && j < M) {
             double s1 = 0.0, s2 = 0.0;
             for (int k = 0; k < 8; ++k) {
@@ -908,6 +991,36 @@ __global__ __launch_bounds__(256) void llgrad_reduce_kernel(const double* __rest
         __syncthreads();
     }
     if (threadIdx.x == 0) out[m] = red[0];
+}
+
+__global__ __launch_bounds__(32) void grad_finalize_kernel(const double* __restrict__ part, int rsplit,
+                                                           const double* __restrict__ Csc, int d, int Mp, int M,
+                                                           const double* __restrict__ invlam,
+                                                           const unsigned char* __restrict__ discrete,
+                                                           const double* __restrict__ mean_grad, double* __restrict__ dmu,
+                                                           double* __restrict__ dvar) {
+    constexpr int BN = 32, NS = 2 * (GRAD_MAX_D + 1);
+    const int c = threadIdx.x, j = blockIdx.x * BN + c;
+    if (j >= M) return;
+    const double* pt = part + (size_t)blockIdx.x * rsplit * NS * BN;
+    double s1 = 0.0, s2 = 0.0;
+    for (int y = 0; y < rsplit; ++y) {
+        s1 += pt[((size_t)y * NS + 0) * BN + c];
+        s2 += pt[((size_t)y * NS + 1) * BN + c];
+    }
+    for (int m = 0; m < d; ++m) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int y = 0; y < rsplit; ++y) {
+            t1 += pt[((size_t)y * NS + 2 + 2 * m) * BN + c];
+            t2 += pt[((size_t)y * NS + 3 + 2 * m) * BN + c];
+        }
+        const double u = Csc[(size_t)m * Mp + j], il = invlam[m];
+        const bool disc = discrete && discrete[m];
+        const double g1 = disc ? 0.0 : (u * s1 - t1) * il;
+        const double g2 = disc ? 0.0 : -2.0 * (u * s2 - t2) * il;
+        dmu[(size_t)j * d + m] = g1 + (mean_grad ? mean_grad[(size_t)j * d + m] : 0.0);
+        dvar[(size_t)j * d + m] = g2;
+    }
 }
 
 // a5: full posterior covariance  Σ = K** − VᵀV + 1e-18·I  (mean_and_cov, gaussian_process.jl:180-184;

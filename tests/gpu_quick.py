@@ -217,7 +217,15 @@ def few_timing(d=8, N=4096):
         for i in range(20):
             g.predict(Xs[:, i:i + M])
         dt = (time.time() - t) / 20
-        print(f"predict M={M} N={N}: {dt*1e3:.3f} ms per call ({M/dt:.0f} evals/s in the reference's call pattern)", flush=True)
+        tg = 0.0
+        if M <= 4096:
+            g.predict_grad(Xs[:, :M])
+            t = time.time()
+            for i in range(5):
+                g.predict_grad(Xs[:, i:i + M])
+            tg = (time.time() - t) / 5
+        print(f"predict M={M} N={N}: {dt*1e3:.3f} ms per call ({M/dt:.0f} evals/s in the reference's call pattern); "
+              f"with gradients {tg*1e3:.3f} ms", flush=True)
 
 
 def batch_big(N=4096, d=8):
