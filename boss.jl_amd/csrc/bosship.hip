@@ -255,7 +255,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
                 const int m = nblk - 1 - kk;
                 if (kk == k && m > 0) {
                     ProfScope ps(c, "potrf_syrk");
-                    hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, kk, m, 1);
+                    hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, kk, m, 1, 0);
                 }
             }
             const int m2 = nblk - (k + 2);                   // block triangle behind the pair
@@ -304,7 +304,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
             if (last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);
             last_rest = -1;
             hipLaunchKernelGGL(potrf_colupd_kernel, dim3(2 * m * (m + 1) + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
-                               m, m);
+                               m, m, 0);
             continue;
         }
         if (!la) {
@@ -316,7 +316,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         // ---- look-ahead: panel chain on `s`, bulk of the trailing update on the side stream ----------
         // the next panel's block column was last written by the side stream's update of step k-1
         if (last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);
-        hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, k, m, 1);
+        hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, k, m, 1, 0);
         last_rest = -1;
         static const int exp_norest = getenv("BOSS_EXP_NOREST") ? atoi(getenv("BOSS_EXP_NOREST")) : 0;   // timing experiments only
         if (m >= 2 && exp_norest != 1) {

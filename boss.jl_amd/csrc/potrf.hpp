@@ -407,13 +407,13 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
 }
 
 __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                              int m, int ncols) {
+                                                              int m, int ncols, int jfirst) {
     // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
     // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
     // (used for the last steps, where one small launch beats the two-stream choreography).
     double* A = Abase + (size_t)blockIdx.z * bstride;
     int t = blockIdx.x;
-    int j = 0;
+    int j = jfirst;                                           // first trailing block column handled (0 = column k+1)
     if (ncols > 1) {
         // column j has 4*(m-j)+1 strips
         while (t >= 4 * (m - j) + 1) {
