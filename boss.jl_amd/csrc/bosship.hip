@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -255,7 +256,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
                 const int m = nblk - 1 - kk;
                 if (kk == k && m > 0) {
                     ProfScope ps(c, "potrf_syrk");
-                    hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, kk, m, 1, 0);
+                    hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, kk, m, 1, 0, 1);
                 }
             }
             const int m2 = nblk - (k + 2);                   // block triangle behind the pair
@@ -283,8 +284,52 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         (void)hipEventRecord(c->ev_fork, s);                 // side stream starts after everything enqueued so far
         (void)hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);
     }
+    static const int small_m = getenv("BOSS_SMALL_M") ? atoi(getenv("BOSS_SMALL_M")) : 12;
+    static const bool no_pairs = getenv("BOSS_NO_PAIRS") && atoi(getenv("BOSS_NO_PAIRS"));
+    int kstart = 0;
+    if (la && !no_pairs && batch == 1 && nblk - 1 > small_m + 2) {
+        // ---- paired look-ahead: the bulk update applies TWO panels at a time (K = 256: half the trailing-matrix
+        // traffic, better tile efficiency, half the events) and has TWO steps of slack:
+        //   even step e:  diag, solve,  column e+1 <- panel e                                   (K = 128)
+        //   odd  step o:  diag, solve,  [bulk(o-2) done]  columns o+1, o+2 <- panels o-1, o     (K = 256)
+        //                 side stream:  bulk(o): columns >= o+3 <- panels o-1, o                 (K = 256)
+        // Every column still receives every earlier panel exactly once; the tail (few block columns left)
+        // falls through to the single-stream steps below, entered at an even step.
+        int last = -1;
+        int k = 0;
+        for (; k + 1 < nblk; k += 2) {
+            if (nblk - 1 - k <= small_m + 1) break;          // tail: switch at an even step
+            for (int kk = k; kk < k + 2; ++kk) {
+                hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, 1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, A, ld, bstride, kk, inv16,
+                                   inv16_bstride, info);
+                const int nrows16 = (Np - (kk + 1) * BLK) / 16 + 1;
+                hipLaunchKernelGGL(potrf_trsm_kernel, dim3(nrows16, 1, 1), dim3(64), 0, s, A, ld, bstride, kk, inv16, inv16_bstride,
+                                   (kk + 1) * BLK);
+                const int m = nblk - 1 - kk;
+                if (kk == k) {
+                    hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, 1), dim3(256), 0, s, A, ld, bstride, kk, m, 1, 0, 1);
+                } else {
+                    if (last >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last], 0);
+                    const int nc = m >= 2 ? 2 : 1;
+                    hipLaunchKernelGGL(potrf_colupd_kernel, dim3((4 * m + 1) + (nc == 2 ? 4 * (m - 1) + 1 : 0), 1, 1), dim3(256), 0, s,
+                                       A, ld, bstride, kk, m, nc, 0, 2);
+                    const int m3 = m - 2;                     // block triangle beyond the two columns just updated
+                    if (m3 > 0) {
+                        (void)hipEventRecord(c->ev_panel[kk], s);
+                        (void)hipStreamWaitEvent(c->side_stream, c->ev_panel[kk], 0);
+                        hipLaunchKernelGGL(potrf_syrk_kernel<2>, dim3(m3 * (m3 + 1) / 2 + m3, 1, 1), dim3(256), 0, c->side_stream, A, ld,
+                                           bstride, kk - 1, kk + 3, m3, 0);
+                        (void)hipEventRecord(c->ev_rest[kk], c->side_stream);
+                        last = kk;
+                    }
+                }
+            }
+        }
+        if (last >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last], 0);
+        kstart = k;
+    }
     int last_rest = -1;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = kstart; k < nblk; ++k) {
         {
             ProfScope ps(c, "potrf_diag");
             hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, batch), dim3(DIAG_THREADS), DIAG_LDS_BYTES, s, A, ld, bstride,
@@ -298,13 +343,12 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         }
         const int m = nblk - 1 - k;
         if (m == 0) break;
-        static const int small_m = getenv("BOSS_SMALL_M") ? atoi(getenv("BOSS_SMALL_M")) : 12;
         if (la && m <= small_m) {
             // few tiles left: one small single-stream launch beats the two-stream choreography
             if (last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);
             last_rest = -1;
             hipLaunchKernelGGL(potrf_colupd_kernel, dim3(2 * m * (m + 1) + m, 1, batch), dim3(256), 0, s, A, ld, bstride, k,
-                               m, m, 0);
+                               m, m, 0, 1);
             continue;
         }
         if (!la) {
@@ -316,7 +360,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
         // ---- look-ahead: panel chain on `s`, bulk of the trailing update on the side stream ----------
         // the next panel's block column was last written by the side stream's update of step k-1
         if (last_rest >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last_rest], 0);
-        hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, k, m, 1, 0);
+        hipLaunchKernelGGL(potrf_colupd_kernel, dim3(4 * m + 1, 1, batch), dim3(256), 0, s, A, ld, bstride, k, m, 1, 0, 1);
         last_rest = -1;
         static const int exp_norest = getenv("BOSS_EXP_NOREST") ? atoi(getenv("BOSS_EXP_NOREST")) : 0;   // timing experiments only
         if (m >= 2 && exp_norest != 1) {

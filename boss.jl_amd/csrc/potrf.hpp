@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
 }
 
 __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                              int m, int ncols, int jfirst) {
+                                                              int m, int ncols, int jfirst, int npan) {
+    // npan = 2: apply the TWO panels k-1, k (K = 256) — the odd steps of the paired look-ahead schedule
     // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
     // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
     // (used for the last steps, where one small launch beats the two-stream choreography).
@@ -423,7 +424,8 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     }
     const int nstr = 4 * (m - j);
     const int R0 = (t < nstr) ? (k + 1 + j) * BLK + t * 32 : (k + 1 + m) * BLK;
-    syrk_tile<RhsG>(A, ld, k, R0, (k + 1 + j) * BLK);
+    if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, R0, (k + 1 + j) * BLK, 2 * BLK);
+    else syrk_tile<RhsG>(A, ld, k, R0, (k + 1 + j) * BLK);
 }
 
 // Block-row variant for boss_gp_append: behind panel k update ONLY block row kb (4 strips of
