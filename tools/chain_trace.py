@@ -1,5 +1,5 @@
 """True device-side timeline of one posterior update (in-kernel s_memrealtime stamps of workgroup 0 of the chain
-kernels; instrumented side build tools/libbosship_tr.so): where does the time between chain kernels go?"""
+kernels; build the instrumented side library first: python tools/build_trace_lib.py): where does the time between chain kernels go?"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
