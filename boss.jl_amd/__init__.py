@@ -11,5 +11,7 @@ from .api import (BossError, Candidates, DomainError, GP, PosDefException, acq_e
 from .problem import (BossOptions, BossProblem, Dirac, Domain, ExperimentData, ExpectedImprovement,  # noqa: F401,E402
                       LinFitness, LogNormal, MvDirac, MvLogNormal, NonlinFitness)
 from .model import HipGaussianProcess, HipGPParams, average_mean  # noqa: F401,E402
+from .gradient_gp import (GradientData, HipGradientGaussianProcess, HipGradientGPParams,  # noqa: F401,E402
+                          join_gradient_slices)
 from .fitter import HipBatchedMAP, HipGradientMAP, MAPParams  # noqa: F401,E402
 from .maximizer import HipBatchAM, HipGradientAM, HipSequentialBatchAM  # noqa: F401,E402

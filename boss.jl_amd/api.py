@@ -34,6 +34,8 @@ SIGNATURES = {
     "boss_gp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_ucp, C.POINTER(C.c_void_p)]),
     "boss_gp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, _c_dp, C.c_int, _c_dp]),
     "boss_gp_sync": (C.c_int, [C.c_void_p, _c_dp]),
+    "boss_ggp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_void_p)]),
+    "boss_ggp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, C.c_double, C.c_int, _c_dp]),
     "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
                               _c_ucp, C.POINTER(C.c_void_p), _c_dp]),
     "boss_gp_set_y": (C.c_int, [C.c_void_p, _c_dp]),
@@ -312,6 +314,40 @@ class GP:
             self.close()
         except Exception:
             pass
+
+
+class GradGP(GP):
+    """One output slice's posterior conditioned on values AND gradients (GradientGaussianProcess,
+    src/models/gradient_gp.jl): X d×n, y n, dY d×n.  `N` is the size of the augmented system n(1+d)."""
+
+    def __init__(self, X, y, dY, kernel="matern52", device: int = 0):
+        lib = load_library()
+        X = _f64(X, 2)
+        y = _f64(np.asarray(y).reshape(-1), 1)
+        dY = np.asfortranarray(np.asarray(dY, dtype=np.float64))
+        self.d, self.n = X.shape
+        if y.shape[0] != self.n or dY.shape != (self.d, self.n):
+            raise ValueError("y must have n entries and dY must be d×n")
+        self.N = self.n * (1 + self.d)
+        self.device = device
+        self.kernel = _kernel_id(kernel)
+        h = C.c_void_p()
+        _check(lib.boss_ggp_create(device, self.kernel, self.d, self.n, _dp(X), _dp(y),
+                                   dY.ctypes.data_as(_c_dp), C.byref(h)))
+        self._h = h
+        self.logpdf = None
+
+    def update(self, lengthscale, amplitude, noise_std, grad_noise_std, sync: bool = True) -> Optional[float]:
+        lam = _f64(np.asarray(lengthscale).reshape(-1), 1)
+        if lam.shape[0] != self.d:
+            raise BossError(BOSS_E_INVALID, "length(lengthscales) must equal x_dim")
+        out = C.c_double(0.0)
+        _check(load_library().boss_ggp_update(self._h, _dp(lam), float(amplitude), float(noise_std), float(grad_noise_std),
+                                              0 if sync else FIT_NO_SYNC, C.byref(out)))
+        if sync:
+            self.logpdf = out.value
+            return out.value
+        return None
 
 
 class Candidates:

@@ -112,6 +112,10 @@ static int get_ctx(int device, Ctx** out) {
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG64>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG32>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG64>::BYTES));
     g_ctx[device] = c;
     *out = c;
     return BOSS_OK;
@@ -175,6 +179,10 @@ struct boss_gp {
     unsigned long long epoch = 0;              // bumped by every boss_gp_update: tracked candidate states go stale
     hipEvent_t dinv_ev = nullptr;              // the side stream finished building Dinv / Dinv2
     bool dinv_pending = false;
+    // gradient-observation posterior (GradientGaussianProcess): npts points, N = npts (1 + d) observations,
+    // Xraw is [d][ldx]; hyp = {α², σ², σ_∂²}
+    bool aug = false;
+    int npts = 0, ldx = 0;
 };
 
 struct boss_cand {
@@ -415,8 +423,10 @@ static void pack_points(std::vector<double>& dst, const double* X, int d, int n,
         }
 }
 
-extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double* X, const double* y,
-                              const unsigned char* discrete, boss_gp_t** out) {
+// npts points of dimension d carrying N observations (N = npts for the plain model, npts (1 + d) with
+// gradient observations); y holds the N observed values in the posterior's own ordering.
+static int gp_create_common(int device, int kernel, int d, int npts, int N, const double* X, const double* y,
+                            const unsigned char* discrete, bool aug, boss_gp_t** out) {
     if (!out) return fail(BOSS_E_INVALID, "out is NULL");
     *out = nullptr;
     if (kernel < 0 || kernel > 2) return fail(BOSS_E_INVALID, "unknown kernel id");
@@ -432,7 +442,10 @@ extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double
     g->Np = round_up(N, PRED_RB);                 // whole 256-row prediction steps (padding = identity)
     g->nblk = g->Np / BLK;
     g->ld = g->Np + RHS_ROWS;
-    const size_t Np = g->Np;
+    g->aug = aug;
+    g->npts = npts;
+    g->ldx = aug ? round_up(npts, 64) : g->Np;
+    const size_t Np = g->Np, ldx = g->ldx;
 #define GALLOC(ptr, bytes)                                        \
     do {                                                          \
         hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));       \
@@ -441,20 +454,20 @@ extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double
             return fail(BOSS_E_ALLOC, "device allocation failed"); \
         }                                                         \
     } while (0)
-    GALLOC(g->Xraw, sizeof(double) * d * Np);
-    GALLOC(g->Xsc, sizeof(double) * d * Np);
+    GALLOC(g->Xraw, sizeof(double) * d * ldx);
+    GALLOC(g->Xsc, sizeof(double) * d * ldx);
     GALLOC(g->y, sizeof(double) * Np);
     GALLOC(g->mean, sizeof(double) * Np);
     GALLOC(g->A, sizeof(double) * (size_t)g->ld * Np);
     GALLOC(g->inv16, sizeof(double) * g->nblk * 8 * 256);
     GALLOC(g->Dinv, sizeof(double) * g->nblk * BLK * BLK);
     GALLOC(g->Dinv2, sizeof(double) * (g->Np / PRED_RB) * PRED_RB * PRED_RB);
-    GALLOC(g->hyp, sizeof(double) * 2);
+    GALLOC(g->hyp, sizeof(double) * 4);
     GALLOC(g->invlam, sizeof(double) * d);
     GALLOC(g->scal, sizeof(double) * 2);
     GALLOC(g->info, sizeof(int));
     if (hipHostMalloc((void**)&g->host_res, 64, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&g->host_par, sizeof(double) * (d + 2), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&g->host_par, sizeof(double) * (d + 4), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&g->par_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->dinv_ev, hipEventDisableTiming) != hipSuccess) {
         gp_release(g);
@@ -473,8 +486,8 @@ extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double
     }
 #undef GALLOC
     std::vector<double> buf;
-    pack_points(buf, X, d, N, (int)Np, g->discrete.empty() ? nullptr : g->discrete.data());
-    HIPCHK(hipMemcpyAsync(g->Xraw, buf.data(), sizeof(double) * d * Np, hipMemcpyHostToDevice, c->stream));
+    pack_points(buf, X, d, npts, (int)ldx, g->discrete.empty() ? nullptr : g->discrete.data());
+    HIPCHK(hipMemcpyAsync(g->Xraw, buf.data(), sizeof(double) * d * ldx, hipMemcpyHostToDevice, c->stream));
     std::vector<double> yb(Np, 0.0);
     std::copy(y, y + N, yb.begin());
     HIPCHK(hipMemcpyAsync(g->y, yb.data(), sizeof(double) * Np, hipMemcpyHostToDevice, c->stream));
@@ -485,8 +498,36 @@ extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double
     return BOSS_OK;
 }
 
+extern "C" int boss_gp_create(int device, int kernel, int d, int N, const double* X, const double* y,
+                              const unsigned char* discrete, boss_gp_t** out) {
+    return gp_create_common(device, kernel, d, N, N, X, y, discrete, false, out);
+}
+
+// GradientGaussianProcess (src/models/gradient_gp.jl): dY is d×n column-major, dY[l + d*j] = ∂y/∂x_l at x_j.
+extern "C" int boss_ggp_create(int device, int kernel, int d, int n, const double* X, const double* y, const double* dY,
+                               boss_gp_t** out) {
+    if (!out) return fail(BOSS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (d < 1 || n < 1 || !X || !y || !dY) return fail(BOSS_E_INVALID, "need d >= 1, n >= 1 and non-NULL X, y, dY");
+    if (d > AUG_MAX_D) return fail(BOSS_E_INVALID, "gradient observations: x_dim above 16 is not supported");
+    if ((long long)n * (1 + d) > 200000) return fail(BOSS_E_INVALID, "augmented system too large (n (1 + d) > 200000)");
+    // `_build_obs_vector` (gradient_gp.jl:288-302): [y_1..n, ∂y/∂x_1 (1..n), …, ∂y/∂x_d (1..n)]
+    std::vector<double> yt((size_t)n * (1 + d));
+    for (int j = 0; j < n; ++j) {
+        yt[j] = y[j];
+        for (int l = 0; l < d; ++l) yt[(size_t)n * (1 + l) + j] = dY[(size_t)j * d + l];
+    }
+    return gp_create_common(device, kernel, d, n, n * (1 + d), X, yt.data(), nullptr, true, out);
+}
+
+#define NOT_FOR_AUG(g)                                                                                            \
+    do {                                                                                                          \
+        if ((g)->aug) return fail(BOSS_E_INVALID, "not available for gradient-observation posteriors (boss_ggp_*)"); \
+    } while (0)
+
 extern "C" int boss_gp_set_y(boss_gp_t* g, const double* y) {
     if (!g || !y) return fail(BOSS_E_INVALID, "NULL argument");
+    NOT_FOR_AUG(g);
     HIPCHK(hipSetDevice(g->ctx->device));
     HIPCHK(hipMemcpyAsync(g->y, y, sizeof(double) * g->N, hipMemcpyHostToDevice, g->ctx->stream));
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
@@ -568,12 +609,20 @@ static int factor_enqueue(boss_gp* g) {
     HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
     {
         ProfScope ps(c, "prep");
-        hipLaunchKernelGGL(scale_points_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc,
-                           (size_t)0, g->invlam, g->d, g->Np);
+        if (!g->aug)
+            hipLaunchKernelGGL(scale_points_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc,
+                               (size_t)0, g->invlam, g->d, g->Np);
         hipLaunchKernelGGL(rhs_rows_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0,
                            g->N, g->Np, g->y, g->mean, (size_t)0, 0);
     }
-    gram_enqueue(c, g->Xsc, 0, g->d, g->N, g->Np, g->kernel, g->hyp, g->A, g->ld, 0, 1);
+    if (g->aug) {
+        ProfScope ps(c, "gram");
+        const long long t64 = g->Np / 64;
+        hipLaunchKernelGGL(aug_gram_kernel, dim3((unsigned)(t64 * (t64 + 1) / 2)), dim3(256), 0, s, (const double*)g->Xraw, g->ldx,
+                           g->d, g->npts, g->N, g->Np, g->kernel, (const double*)g->hyp, (const double*)g->invlam, g->A, g->ld);
+    } else {
+        gram_enqueue(c, g->Xsc, 0, g->d, g->N, g->Np, g->kernel, g->hyp, g->A, g->ld, 0, 1);
+    }
     potrf_enqueue(c, g->A, g->ld, g->Np, 1, 0, g->inv16, 0, g->info);
     dinv_eager(g);
     {
@@ -589,6 +638,7 @@ static int factor_enqueue(boss_gp* g) {
 extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double amplitude, double noise_std,
                               const double* mean_X, int flags, double* logpdf_out) {
     if (!g) return fail(BOSS_E_INVALID, "gp is NULL");
+    NOT_FOR_AUG(g);
     int rc = validate_hyper(g->d, lengthscale, amplitude, noise_std);
     if (rc) return rc;
     Ctx* c = g->ctx;
@@ -619,6 +669,42 @@ extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double am
         HIPCHK(hipMemsetAsync(g->mean, 0, sizeof(double) * g->Np, s));
         g->has_mean = false;
     }
+    rc = factor_enqueue(g);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    g->pending = true;
+    if (flags & BOSS_FIT_NO_SYNC) return BOSS_OK;
+    return gp_finish(g, logpdf_out);
+}
+
+// model_posterior_slice / data_loglike of GradientGaussianProcess (gradient_gp.jl:307-329, :367-397):
+// augmented Gram, Cholesky, α-solve and log marginal likelihood under (λ, α, σ, σ_∂).
+extern "C" int boss_ggp_update(boss_gp_t* g, const double* lengthscale, double amplitude, double noise_std,
+                               double grad_noise_std, int flags, double* logpdf_out) {
+    if (!g) return fail(BOSS_E_INVALID, "gp is NULL");
+    if (!g->aug) return fail(BOSS_E_INVALID, "handle was not created by boss_ggp_create");
+    int rc = validate_hyper(g->d, lengthscale, amplitude, noise_std);
+    if (rc) return rc;
+    if (!(grad_noise_std >= 0.0)) return fail(BOSS_E_INVALID, "grad_noise_std must be >= 0");
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    hipStream_t s = c->stream;
+    g->fitted = false;
+    g->have_dinv = false;
+    ++g->epoch;
+    HIPCHK(hipEventSynchronize(g->par_ev));
+    double* invlam = g->host_par;
+    double* hyp = g->host_par + g->d;
+    for (int k = 0; k < g->d; ++k) invlam[k] = 1.0 / (lengthscale[k] + MIN_PARAM_VALUE);   // gradient_gp.jl:128-131
+    const double amp = amplitude + MIN_PARAM_VALUE, sig = noise_std + MIN_PARAM_VALUE, sgd = grad_noise_std + MIN_PARAM_VALUE;
+    hyp[0] = amp * amp;
+    hyp[1] = sig * sig;                                      // :200-204
+    hyp[2] = sgd * sgd;
+    g->amp2 = hyp[0];
+    HIPCHK(hipMemcpyAsync(g->invlam, invlam, sizeof(double) * g->d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->hyp, hyp, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(g->par_ev, s));
     rc = factor_enqueue(g);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -696,6 +782,7 @@ static int gp_grow(boss_gp* g, int Nnew) {
 // factorisation.  The handle is left unfitted: call boss_gp_update afterwards.
 extern "C" int boss_gp_reserve(boss_gp_t* g, int N_total) {
     if (!g || N_total < 1) return fail(BOSS_E_INVALID, "bad arguments");
+    NOT_FOR_AUG(g);
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);
@@ -710,6 +797,7 @@ extern "C" int boss_gp_reserve(boss_gp_t* g, int N_total) {
 extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const double* y_new, const double* mean_new,
                               double* logpdf_out) {
     if (!g || n < 1 || !X_new || !y_new) return fail(BOSS_E_INVALID, "need a handle, n >= 1 and non-NULL X_new, y_new");
+    NOT_FOR_AUG(g);
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);
@@ -1040,6 +1128,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     static const bool no_few = getenv("BOSS_NO_FEW") && atoi(getenv("BOSS_NO_FEW"));
     static const int few_max_tiles = getenv("BOSS_FEW_MAX_TILES") ? atoi(getenv("BOSS_FEW_MAX_TILES")) : 128;
     const int ftiles = (cd->M + 31) / 32;
+    const size_t aug_lds = sizeof(double) * ((size_t)g->d * (64 + 256) + g->d);
     if (ftiles <= few_max_tiles && g->Np >= 4 * PRED_RB && g->d <= 64 && !no_few && (BN == 32 || for_grad)) {
         // few candidates (the fused kernel would occupy `ftiles` of 256 CUs for its whole latency):
         // right-looking substitution, every 256-row step spread over the chip
@@ -1053,16 +1142,38 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         double* ssmz = R + (size_t)ftiles * g->Np * 32;
         double* V = (double*)c->vscratch.p;
         (void)hipMemsetAsync(ssmz, 0, sizeof(double) * 64 * ftiles, s);
-        hipLaunchKernelGGL(kstar_rows_kernel, dim3(g->Np / 256, ftiles), dim3(256), sizeof(double) * g->d * 32, s,
-                           (const double*)g->Xsc, g->Np, g->N, (const double*)Csc, g->d, Mp, g->kernel, g->amp2, R);
+        if (g->aug)
+            hipLaunchKernelGGL(aug_kstar_kernel, dim3(g->Np / 256, ftiles), dim3(256), aug_lds, s, (const double*)g->Xraw, g->ldx,
+                               g->d, g->npts, g->N, g->Np, (const double*)cd->Craw, Mp, g->kernel, g->amp2,
+                               (const double*)g->invlam, R, 32);
+        else
+            hipLaunchKernelGGL(kstar_rows_kernel, dim3(g->Np / 256, ftiles), dim3(256), sizeof(double) * g->d * 32, s,
+                               (const double*)g->Xsc, g->Np, g->N, (const double*)Csc, g->d, Mp, g->kernel, g->amp2, R);
         for (int ib = 0; ib < nb; ++ib) {
             hipLaunchKernelGGL(few_finish_kernel<G>, dim3(ftiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->A,
                                g->ld, g->Np, ib, (const double*)R, (const double*)g->Dinv2, V, ssmz, ib == nb - 1 ? 1 : 0,
-                               mean_s_dev, cd->M, g->amp2, mu, var);
+                               mean_s_dev, cd->M, g->amp2, mu, var, g->aug ? 1 : 0);
             const int nupd = (nb - 1 - ib) * (PRED_RB / BLK);
             if (nupd > 0)
                 hipLaunchKernelGGL(few_update_kernel<GU>, dim3(nupd, ftiles), dim3(GU::NTHREADS), 0, s, (const double*)g->A, g->ld,
                                    g->Np, ib, (const double*)V, R);
+        }
+        HIPCHK(hipGetLastError());
+        return BOSS_OK;
+    }
+    if (g->aug) {
+        ProfScope ps(c, "predict");
+        double* V = (double*)c->vscratch.p;
+        hipLaunchKernelGGL(aug_kstar_kernel, dim3(g->Np / 256, tiles), dim3(256), aug_lds, s, (const double*)g->Xraw, g->ldx, g->d,
+                           g->npts, g->N, g->Np, (const double*)cd->Craw, Mp, g->kernel, g->amp2, (const double*)g->invlam, V, BN);
+        if (BN == 32) {
+            typedef PredG32 G;
+            hipLaunchKernelGGL((predict_kernel<G, true>), dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
+                               g->N, g->Dinv2, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, V, mean_s_dev, cd->M, mu, var, dbg);
+        } else {
+            typedef PredG64 G;
+            hipLaunchKernelGGL((predict_kernel<G, true>), dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
+                               g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, V, mean_s_dev, cd->M, mu, var, dbg);
         }
         HIPCHK(hipGetLastError());
         return BOSS_OK;
@@ -1088,6 +1199,7 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
     if (!g || !Xs || !mu || !var) return fail(BOSS_E_INVALID, "NULL argument");
     if (M < 1) return fail(BOSS_E_INVALID, "M must be >= 1");
     if (bad_index) *bad_index = -1;
+    if (g->aug && mean_Xs) return fail(BOSS_E_INVALID, "gradient-observation posteriors take no prior mean (gradient_gp.jl:334-337)");
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1220,6 +1332,7 @@ static int grad_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_de
 extern "C" int boss_gp_predict_grad(boss_gp_t* g, int M, const double* Xs, const double* mean_Xs, const double* mean_grad,
                                     double* mu, double* var, double* dmu, double* dvar, long* bad_index) {
     if (!g || !Xs || !mu || !var || !dmu || !dvar) return fail(BOSS_E_INVALID, "NULL argument");
+    NOT_FOR_AUG(g);
     if (M < 1) return fail(BOSS_E_INVALID, "M must be >= 1");
     if (bad_index) *bad_index = -1;
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
@@ -1279,6 +1392,7 @@ extern "C" int boss_acq_ei_grad(int P, boss_gp_t* const* gps, int M, const doubl
     if (P < 1 || !gps || M < 1 || !Xs || !fit_coefs || !acq_out || !dacq_out) return fail(BOSS_E_INVALID, "bad arguments");
     for (int p = 0; p < P; ++p) {
         if (!gps[p]) return fail(BOSS_E_INVALID, "NULL posterior handle");
+        NOT_FOR_AUG(gps[p]);
         if (gps[p]->ctx != gps[0]->ctx || gps[p]->d != gps[0]->d)
             return fail(BOSS_E_INVALID, "all handles must live on one device and share x_dim");
         if (!gps[p]->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
@@ -1347,6 +1461,7 @@ extern "C" int boss_acq_ei_grad(int P, boss_gp_t* const* gps, int M, const doubl
 extern "C" int boss_gp_predict_cov(boss_gp_t* g, int M, const double* Xs, const double* mean_Xs, double* mu,
                                    double* cov, long* bad_index) {
     if (!g || !Xs || !mu || !cov) return fail(BOSS_E_INVALID, "NULL argument");
+    NOT_FOR_AUG(g);
     if (M < 1) return fail(BOSS_E_INVALID, "M must be >= 1");
     if (bad_index) *bad_index = -1;
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
@@ -1544,6 +1659,7 @@ extern "C" int boss_acq_ei_moments(int device, int P, int S, int M, const double
 // ------------------------------------------------------------------------------------------
 extern "C" int boss_gp_loglike_grad(boss_gp_t* g, double* logpdf_out, double* grad_out) {
     if (!g || !grad_out) return fail(BOSS_E_INVALID, "NULL argument");
+    NOT_FOR_AUG(g);
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);
@@ -1638,6 +1754,7 @@ extern "C" int boss_track_create(boss_gp_t* g, const boss_cand_t* cand, const do
     if (!out) return fail(BOSS_E_INVALID, "out is NULL");
     *out = nullptr;
     if (!g || !cand) return fail(BOSS_E_INVALID, "NULL argument");
+    NOT_FOR_AUG(g);
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
     if (cand->ctx != g->ctx || cand->d != g->d) return fail(BOSS_E_INVALID, "candidates and posterior must share device and x_dim");
     Ctx* c = g->ctx;

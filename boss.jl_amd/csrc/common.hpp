@@ -73,6 +73,16 @@ __device__ __forceinline__ double kappa_prime_over_r_r2(int kern, double r2) {
     return -(5.0 / 3.0) * (1.0 + s) * exp(-s);
 }
 
+// g(r) = h'(r)/r: the second radial factor of the kernel's mixed second derivative,
+// ∂²k/∂x_l∂x'_m = −α² [ h(r) δ_lm/λ_l² + g(r) s_l s_m ],  s = (x − x') ⊘ λ²   (gradient_gp.jl:143-159 obtains
+// it by ForwardDiff).  Matérn-3/2 is singular at r = 0; the reference never evaluates it there (:151-152).
+__device__ __forceinline__ double kappa_second_r2(int kern, double r2) {
+    if (kern == KERN_SQEXP) return exp(-0.5 * r2);
+    double r = sqrt(r2);
+    if (kern == KERN_MATERN32) return 5.196152422706632 * exp(-1.7320508075688772 * r) / r;
+    return (25.0 / 3.0) * exp(-2.23606797749979 * r);
+}
+
 __device__ __forceinline__ double normcdf_dev(double z) {   // StatsFuns.normcdf = erfc(-z/√2)/2
     return 0.5 * erfc(-z * 0.7071067811865476);
 }

@@ -82,6 +82,115 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs
 }
 
 // ------------------------------------------------------------------------------------------
+// GradientGaussianProcess (src/models/gradient_gp.jl): n points observed as values AND
+// gradients give an n(1+d) square system over the ordering [f(x_1..n), ∂_1 f(x_1..n), …, ∂_d f(x_1..n)].
+// Observation a = l·n + i is (l, point i): l = 0 the value, l ≥ 1 the derivative along coordinate l−1.
+// Only the Gram build and the cross-covariances differ from the plain model; the factorisation, the
+// substitutions and the acquisition kernels run unchanged on the larger matrix.
+// Points are RAW here (P[k*ldx + j]); il = 1/(λ+1e-8).
+// ------------------------------------------------------------------------------------------
+constexpr int AUG_MAX_D = 16;
+constexpr double ISAPPROX_RTOL2 = 2.220446049250313e-16;     // Julia `≈` on Float64 vectors: rtol = √eps, squared
+
+// One entry of `_build_augmented_kernel` (gradient_gp.jl:175-199) / `_build_cross_cov` (:221-243):
+// row observation (lr, xi), column observation (lc, xj).  The value block uses the points as given; the
+// derivative blocks are evaluated at (xi, xj + 1e-8) when xi ≈ xj (:148-152, :233).
+__device__ __forceinline__ double aug_entry(int kern, double amp2, int d, const double* il, const double* xi, int si,
+                                            const double* xj, int sj, int lr, int lc) {
+    double du2 = 0.0, ni = 0.0, nj = 0.0, r2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double a = xi[k * si], b = xj[k * sj], u = a - b, t = u * il[k];
+        du2 = __builtin_fma(u, u, du2);
+        ni = __builtin_fma(a, a, ni);
+        nj = __builtin_fma(b, b, nj);
+        r2 = __builtin_fma(t, t, r2);
+    }
+    if (lr == 0 && lc == 0) return amp2 * kappa_r2(kern, r2);
+    double eps = 0.0;
+    if (du2 <= ISAPPROX_RTOL2 * fmax(ni, nj)) {
+        eps = MIN_PARAM_VALUE;
+        r2 = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double t = (xi[k * si] - (xj[k * sj] + eps)) * il[k];
+            r2 = __builtin_fma(t, t, r2);
+        }
+    }
+    const double h = kappa_prime_over_r_r2(kern, r2);
+    if (lr == 0 || lc == 0) {
+        const int m = (lr == 0 ? lc : lr) - 1;
+        const double s = (xi[m * si] - (xj[m * sj] + eps)) * il[m] * il[m];
+        return (lr == 0) ? -amp2 * h * s : amp2 * h * s;     // ∂k/∂(xj)_m  |  ∂k/∂(xi)_l
+    }
+    const int l = lr - 1, m = lc - 1;
+    const double sl = (xi[l * si] - (xj[l * sj] + eps)) * il[l] * il[l];
+    const double sm = (xi[m * si] - (xj[m * sj] + eps)) * il[m] * il[m];
+    double v = kappa_second_r2(kern, r2) * sl * sm;
+    if (l == m) v = __builtin_fma(h, il[l] * il[l], v);
+    return -amp2 * v;
+}
+
+// Lower 64×64 tiles of the augmented matrix.  `cholesky(Symmetric(K))` (:209,:325) reads the UPPER
+// triangle, so the stored entry (a, b), a ≥ b, is the reference's K[b, a].  hyp = {α², σ², σ_∂²};
+// padding rows/columns = identity.
+__global__ __launch_bounds__(256) void aug_gram_kernel(const double* __restrict__ Xraw, int ldx, int d, int n, int N, int Np,
+                                                       int kern, const double* __restrict__ hyp,
+                                                       const double* __restrict__ invlam, double* __restrict__ A, int ld) {
+    __shared__ double xa[AUG_MAX_D][64], xb[AUG_MAX_D][64], il[AUG_MAX_D];
+    __shared__ int la[64], lb[64];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    if (tid < 128) {
+        const int c = tid & 63, obs = (tid < 64 ? bi : bj) * 64 + c;
+        const int l = obs < N ? obs / n : -1, pt = obs < N ? obs - l * n : 0;
+        if (tid < 64) la[c] = l; else lb[c] = l;
+        for (int k = 0; k < d; ++k) (tid < 64 ? xa : xb)[k][c] = Xraw[(size_t)k * ldx + pt];
+    }
+    if (tid >= 128 && tid < 128 + d) il[tid - 128] = invlam[tid - 128];
+    __syncthreads();
+    const double amp2 = hyp[0];
+    const int r = tid & 63, cg = tid >> 6, a = bi * 64 + r;
+#pragma unroll 1
+    for (int c = 0; c < 16; ++c) {
+        const int cc = cg * 16 + c, b = bj * 64 + cc;
+        if (a < b) continue;
+        double v;
+        if (a < N && b < N) {
+            v = aug_entry(kern, amp2, d, il, &xb[0][cc], 64, &xa[0][r], 64, lb[cc], la[r]);
+            if (a == b) v += (la[r] == 0) ? hyp[1] : hyp[2];
+        } else {
+            v = (a == b) ? 1.0 : 0.0;
+        }
+        A[(size_t)b * ld + a] = v;
+    }
+}
+
+// Cross-covariances of `_build_cross_cov` for every candidate, written where the substitution kernels
+// expect their right-hand side: out[tile][row][BN] (the V slabs of predict_kernel<G, true>, or the residual
+// array of the few-candidates path).  One training observation per thread; padding rows = 0.
+__global__ __launch_bounds__(256) void aug_kstar_kernel(const double* __restrict__ Xraw, int ldx, int d, int n, int N, int Np,
+                                                        const double* __restrict__ Craw, int Mp, int kern, double amp2,
+                                                        const double* __restrict__ invlam, double* __restrict__ out, int BN) {
+    extern __shared__ double sm[];                           // cs[d][BN] | xt[d][256] | il[d]
+    double* cs = sm;
+    double* xt = cs + d * BN;
+    double* il = xt + d * 256;
+    const int tid = threadIdx.x, c0 = blockIdx.y * BN;
+    out += (size_t)blockIdx.y * Np * BN;
+    const int row = blockIdx.x * 256 + tid;
+    const int l = row < N ? row / n : -1, pt = row < N ? row - l * n : 0;
+    for (int idx = tid; idx < d * BN; idx += 256) cs[idx] = Craw[(size_t)(idx / BN) * Mp + c0 + (idx % BN)];
+    for (int k = 0; k < d; ++k) xt[k * 256 + tid] = Xraw[(size_t)k * ldx + pt];
+    if (tid < d) il[tid] = invlam[tid];
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < BN; ++c)
+        out[(size_t)row * BN + c] = (l >= 0) ? aug_entry(kern, amp2, d, il, cs + c, BN, xt + tid, 256, 0, l) : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
 // K4-K7 fused prediction.  One workgroup owns BN candidates and walks the row blocks of L:
 //     R_i = K*_i − Σ_{j<i} L_ij V_j          (MFMA GEMM, V_j re-read from its own scratch slab)
 //     V_i = Dinv_i · R_i                      (MFMA GEMM, R_i resident in LDS)
@@ -101,7 +210,9 @@ struct PredictLds {
 // Both GEMMs stream their A operand (L row block / Dinv_i) straight from L2 through a register
 // ring; GEMM1's B operand is the workgroup's own V slab (global, candidate-contiguous), GEMM2's
 // B operand is the R tile in LDS.  Three barriers per row block, none inside the GEMMs.
-template <class G>
+// PRE: the right-hand side K* is not evaluated here but was written to the workgroup's V slab beforehand
+// (gradient-observation posteriors, aug_kstar_kernel); block ib's rows are consumed before V_ib overwrites them.
+template <class G, bool PRE = false>
 __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
                                                       const double* __restrict__ Dinv,
                                                       const double* __restrict__ Xsc,
@@ -145,7 +256,7 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
             for (int n = 0; n < TN; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) r2[m][n][i] = 0.0;
-        for (int kd = 0; kd < ((dbg & 1) ? 0 : d); ++kd) {
+        for (int kd = 0; kd < ((dbg & 1) || PRE ? 0 : d); ++kd) {
             double xr[TM], xc[TN][4];
 #pragma unroll
             for (int m = 0; m < TM; ++m) xr[m] = Xsc[(size_t)kd * Np + ib * RB + G::row_of(wr, m, lane)];
@@ -171,7 +282,9 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
             for (int n = 0; n < TN; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    double ks = (live && !(dbg & 1)) ? amp2 * kappa_r2(kern, r2[m][n][i]) : 0.0;
+                    double ks;
+                    if constexpr (PRE) ks = V[(size_t)(ib * RB + row) * BN + G::col_of(wc, n, i, lane)];
+                    else ks = (live && !(dbg & 1)) ? amp2 * kappa_r2(kern, r2[m][n][i]) : 0.0;
                     Rs[row * LDR + G::col_of(wc, n, i, lane)] = ks - acc[m][n][i];
                 }
         }
@@ -238,7 +351,8 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
         const int j = c0 + tid;
         if (j < M) {
             mu_out[j] = (mean_s ? mean_s[j] : 0.0) + z;
-            var_out[j] = amp2 - s + PREDICT_JITTER;
+            if constexpr (PRE) var_out[j] = fmax(0.0, amp2 - s);           // gradient_gp.jl:346: no jitter, clamped at 0
+            else var_out[j] = amp2 - s + PREDICT_JITTER;
         }
     }
 }
@@ -316,7 +430,8 @@ __global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* _
                                                                  const double* __restrict__ Dinv2, double* __restrict__ V,
                                                                  double* __restrict__ ssmz, int last,
                                                                  const double* __restrict__ mean_s, int M, double amp2,
-                                                                 double* __restrict__ mu_out, double* __restrict__ var_out) {
+                                                                 double* __restrict__ mu_out, double* __restrict__ var_out,
+                                                                 int aug) {
     constexpr int RB = G::BM, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR, BN = 32;
     extern __shared__ double lds[];
     double* Rs = lds;
@@ -387,7 +502,7 @@ __global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* _
         ssmz[BN + tid] = z;
         if (last && c0 + tid < M) {
             mu_out[c0 + tid] = (mean_s ? mean_s[c0 + tid] : 0.0) + z;
-            var_out[c0 + tid] = amp2 - s + PREDICT_JITTER;
+            var_out[c0 + tid] = aug ? fmax(0.0, amp2 - s) : amp2 - s + PREDICT_JITTER;
         }
     }
 }

@@ -119,6 +119,31 @@ int boss_gp_loglike_grad(boss_gp_t* gp, double* logpdf_out, double* grad_out);
  * and z = L \ (y - m) (N). Either pointer may be NULL. */
 int boss_gp_get_factor(const boss_gp_t* gp, double* L_out, double* z_out);
 
+/* ---- gradient observations ----------------------------------------------------
+ * Replaces: GradientGaussianProcess — model_posterior_slice (src/models/gradient_gp.jl:307-329),
+ *           data_loglike (:367-397), mean / var / mean_and_var (:334-361).
+ *
+ * Every point carries its value and its gradient: n points give an n(1+d) system over the
+ * observation ordering [y_1..n, dy/dx_1 (1..n), ..., dy/dx_d (1..n)] (_build_obs_vector, :288-302).
+ * boss_ggp_create keeps one output slice resident:
+ *   X   d×n,  y  n,  dY  d×n column-major (dY[l + d*j] = dy/dx_l at x_j — `data.dY[slice, :, :]`).
+ * boss_ggp_update builds the augmented Gram matrix (_build_augmented_kernel, :175-210: value, first and
+ * mixed second derivatives of the kernel, evaluated at (x_i, x_j + 1e-8) for coincident points; noise
+ * (sigma+1e-8)^2 on the value block and (grad_noise_std+1e-8)^2 on the gradient blocks; the upper
+ * triangle is the one that counts, `Symmetric(K)`), factorises it and returns
+ *   logpdf_out = -(y~' K^-1 y~ + log|K| + n(1+d) log 2pi)/2.
+ * The model's mean function is not used by the reference for this model and is not taken here.
+ * The returned handle is a boss_gp_t: boss_gp_sync, boss_gp_predict (mu = k*'alpha, var = max(0, k(x,x) - |L^-1 k*|^2),
+ * k* from _build_cross_cov :221-243; mean_Xs must be NULL), boss_gp_get_factor, boss_acq_ei, boss_acq_ei_moments
+ * and boss_gp_free work on it; the entry points that assume value-only observations (boss_gp_update,
+ * boss_gp_set_y, boss_gp_append, boss_gp_reserve, boss_gp_predict_grad, boss_gp_predict_cov,
+ * boss_gp_loglike_grad, boss_acq_ei_grad, boss_track_create) return BOSS_E_INVALID.
+ * Limits: d <= 16, n(1+d) <= 200000. */
+int boss_ggp_create(int device, int kernel, int d, int n, const double* X, const double* y, const double* dY,
+                    boss_gp_t** out);
+int boss_ggp_update(boss_gp_t* gp, const double* lengthscale, double amplitude, double noise_std,
+                    double grad_noise_std, int flags, double* logpdf_out);
+
 /* ---- batched log-likelihood -----------------------------------------------------------
  * Replaces: the `loglike.(samples)` loop of SamplingMAP (src/model_fitters/sampling.jl:59-78) and the
  * per-sample likelihood calls of OptimizationMAP / TuringBI (src/model_fitters/optimization.jl:153-160,

@@ -583,3 +583,136 @@ def ei_acquisition_grad(posts: Sequence[GPPosterior], Xs, fit_coefs, y_max, best
 def argmax_first(vals):
     """Julia `argmax` (sampling.jl:36-39): first index of the maximum."""
     return int(np.argmax(np.asarray(vals)))
+
+
+# ------------------------------------------------------------------------------------------
+# GradientGaussianProcess (SURVEY §8f4): a GP conditioned on function values AND gradients,
+# src/models/gradient_gp.jl.  The reference obtains the derivative blocks by ForwardDiff through
+# KernelFunctions (:143-159); ForwardDiff is exact to rounding, so the analytic derivatives of the
+# radial profiles below ARE what it computes.  The reference holds no tests or fixtures for this
+# model: the restatement is pinned by finite differences of the plain kernel only
+# (tests/test_oracle_crosscheck.py) — PARITY UNPINNED beyond that.
+# ------------------------------------------------------------------------------------------
+def kappa_second(kernel: int, r: np.ndarray) -> np.ndarray:
+    """g(r) = h'(r)/r with h = κ'/r:  SqExp e^{-r²/2};  Matern52 (25/3) e^{-√5 r};
+    Matern32 3√3 e^{-√3 r}/r (singular at r = 0 — the Matérn-3/2 cusp the reference steps around
+    by perturbing one argument, gradient_gp.jl:151-152)."""
+    r = np.asarray(r, dtype=np.float64)
+    if kernel == SQEXP:
+        return np.exp(-0.5 * r * r)
+    if kernel == MATERN52:
+        return (25.0 / 3.0) * np.exp(-_SQRT5 * r)
+    if kernel == MATERN32:
+        return 3.0 * _SQRT3 * np.exp(-_SQRT3 * r) / r
+    raise ValueError(f"unknown kernel id {kernel}")
+
+
+_ISAPPROX_RTOL = math.sqrt(np.finfo(np.float64).eps)     # Julia isapprox default for Float64 vectors
+
+
+def _isapprox(xi: np.ndarray, xj: np.ndarray) -> bool:
+    """Julia `xi ≈ xj` for vectors: norm(xi - xj) <= rtol * max(norm(xi), norm(xj)), atol = 0."""
+    return float(np.linalg.norm(xi - xj)) <= _ISAPPROX_RTOL * max(float(np.linalg.norm(xi)), float(np.linalg.norm(xj)))
+
+
+def _kernel_and_derivs(kernel: int, lam: np.ndarray, amp2: float, xi: np.ndarray, xj: np.ndarray):
+    """gradient_gp.jl:143-159: (k, ∂k/∂xi, ∂k/∂xj, ∂²k/∂xi∂xjᵀ) of k = α² κ(‖(xi−xj)⊘λ‖); the value at the
+    given points, the derivatives at (xi, xj + 1e-8) when xi ≈ xj."""
+    u = xi - xj
+    k_val = amp2 * float(kappa(kernel, np.sqrt(np.sum((u / lam) ** 2))))
+    if _isapprox(xi, xj):
+        u = xi - (xj + MIN_PARAM_VALUE)
+    r = float(np.sqrt(np.sum((u / lam) ** 2)))
+    h = float(kappa_prime_over_r(kernel, np.float64(r)))
+    g = float(kappa_second(kernel, np.float64(r)))
+    s = u / lam ** 2
+    dxi = amp2 * h * s
+    d2 = -amp2 * (h * np.diag(1.0 / lam ** 2) + g * np.outer(s, s))
+    return k_val, dxi, -dxi, d2
+
+
+def augmented_kernel_matrix(kernel: int, X, lengthscale, amplitude: float, noise_std: float, grad_noise_std: float):
+    """gradient_gp.jl:175-210 `_build_augmented_kernel`: the n(1+d) square matrix over the observation
+    ordering [f(x_1..n), ∂f/∂x_1(x_1..n), …, ∂f/∂x_d(x_1..n)], noise σ² on the function block's diagonal
+    and σ_∂² on the gradient blocks' (+1e-8 on every parameter, :128-131,:200-204)."""
+    kernel = KERNEL_NAMES.get(kernel, kernel) if isinstance(kernel, str) else kernel
+    X = np.asarray(X, dtype=np.float64)
+    d, n = X.shape
+    lam = np.asarray(lengthscale, dtype=np.float64) + MIN_PARAM_VALUE
+    amp2 = (float(amplitude) + MIN_PARAM_VALUE) ** 2
+    N = n * (1 + d)
+    K = np.zeros((N, N))
+    for i in range(n):
+        for j in range(n):
+            k_val, dxi, dxj, d2 = _kernel_and_derivs(kernel, lam, amp2, X[:, i], X[:, j])
+            K[i, j] = k_val
+            for l in range(d):
+                K[i, n + l * n + j] = dxj[l]
+                K[n + l * n + i, j] = dxi[l]
+                for m in range(d):
+                    K[n + l * n + i, n + m * n + j] = d2[l, m]
+    K[np.arange(n), np.arange(n)] += (float(noise_std) + MIN_PARAM_VALUE) ** 2
+    K[np.arange(n, N), np.arange(n, N)] += (float(grad_noise_std) + MIN_PARAM_VALUE) ** 2
+    # `Symmetric(K)` (:209) reads the UPPER triangle; the perturbed entries of coincident pairs are not symmetric
+    return np.triu(K) + np.triu(K, 1).T
+
+
+def augmented_cross_cov(kernel: int, X, lengthscale, amplitude: float, Xs):
+    """gradient_gp.jl:213-243 `_build_cross_cov` for every column of Xs: N_aug × M matrix
+    [k(x*, x_j); ∂k(x*, x_j)/∂(x_j)_l], the derivative taken at x_j + 1e-8 when x* ≈ x_j."""
+    kernel = KERNEL_NAMES.get(kernel, kernel) if isinstance(kernel, str) else kernel
+    X = np.asarray(X, dtype=np.float64)
+    Xs = np.asarray(Xs, dtype=np.float64)
+    if Xs.ndim == 1:
+        Xs = Xs[:, None]
+    d, n = X.shape
+    lam = np.asarray(lengthscale, dtype=np.float64) + MIN_PARAM_VALUE
+    amp2 = (float(amplitude) + MIN_PARAM_VALUE) ** 2
+    out = np.zeros((n * (1 + d), Xs.shape[1]))
+    for c in range(Xs.shape[1]):
+        for j in range(n):
+            k_val, _, dxj, _ = _kernel_and_derivs(kernel, lam, amp2, Xs[:, c], X[:, j])
+            out[j, c] = k_val
+            out[n + np.arange(d) * n + j, c] = dxj
+    return out
+
+
+def augmented_obs_vector(y, dY):
+    """gradient_gp.jl:288-302 `_build_obs_vector`: [y_1..n, ∂y/∂x_1 (1..n), …, ∂y/∂x_d (1..n)];  dY is d×n."""
+    return np.concatenate([np.asarray(y, dtype=np.float64)] + [np.asarray(dY, dtype=np.float64)[l, :] for l in range(np.shape(dY)[0])])
+
+
+@dataclass
+class GradientGPPosterior:
+    kernel: int
+    X: np.ndarray
+    lengthscale: np.ndarray
+    amplitude: float
+    L: np.ndarray           # lower Cholesky factor of the augmented matrix
+    alpha: np.ndarray       # K_aug⁻¹ ỹ
+    logpdf: float
+
+
+def gradient_gp_fit(X, y, dY, kernel, lengthscale, amplitude, noise_std, grad_noise_std) -> GradientGPPosterior:
+    """gradient_gp.jl:307-329 `model_posterior_slice` and :367-397 `data_loglike` (the model's mean is
+    not used by either)."""
+    kernel = KERNEL_NAMES.get(kernel, kernel) if isinstance(kernel, str) else kernel
+    yt = augmented_obs_vector(y, dY)
+    K = augmented_kernel_matrix(kernel, X, lengthscale, amplitude, noise_std, grad_noise_std)
+    try:
+        L = sla.cholesky(K, lower=True, check_finite=False)
+    except np.linalg.LinAlgError as e:
+        raise PosDefException(str(e))
+    alpha = sla.cho_solve((L, True), yt, check_finite=False)
+    ll = -0.5 * (float(yt @ alpha) + 2.0 * float(np.sum(np.log(np.diag(L)))) + len(yt) * math.log(2.0 * math.pi))
+    return GradientGPPosterior(kernel, np.asarray(X, dtype=np.float64), np.asarray(lengthscale, dtype=np.float64),
+                               float(amplitude), L, alpha, ll)
+
+
+def gradient_gp_mean_and_var(post: GradientGPPosterior, Xs):
+    """gradient_gp.jl:334-361: μ = k*·α,  σ² = max(0, k(x*,x*) − ‖L⁻¹k*‖²)  (no jitter, no mean function)."""
+    Ks = augmented_cross_cov(post.kernel, post.X, post.lengthscale, post.amplitude, Xs)
+    mu = Ks.T @ post.alpha
+    V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
+    amp2 = (post.amplitude + MIN_PARAM_VALUE) ** 2
+    return mu, np.maximum(0.0, amp2 - np.sum(V * V, axis=0))

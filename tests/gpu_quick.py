@@ -276,6 +276,60 @@ def multi_output(N=2048, d=6, M=8192):
     print(f"multi-output N={N} P=2 M={M}: fit {t_fit*1e3:.2f} ms, acq {t_acq*1e3:.2f} ms ({M/t_acq/1e6:.2f} M evals/s)  |dacq|={np.abs(acq[:256]-want).max():.1e}", flush=True)
 
 
+def grad_problem(d, n, seed=3):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (d, n))
+    w = np.linspace(1.0, 2.0, d)[:, None]
+    y = np.sin(2 * np.pi * w * X).sum(0) / np.sqrt(d)
+    dY = 2 * np.pi * w * np.cos(2 * np.pi * w * X) / np.sqrt(d)
+    return X, y, dY
+
+
+def ggp_parity(d, n, M, kernel, dup=False):
+    X, y, dY = grad_problem(d, n)
+    if dup:
+        X[:, 1] = X[:, 0]
+    Xs = np.random.default_rng(5).uniform(0, 1, (d, M))
+    Xs[:, 0] = X[:, 2]                                   # a candidate on a training point: the perturbed derivative entries
+    lam = np.full(d, 0.4)
+    t = time.time()
+    post = O.gradient_gp_fit(X, y, dY, kernel, lam, 1.2, 0.05, 0.1)
+    mu_o, var_o = O.gradient_gp_mean_and_var(post, Xs)
+    t_cpu = time.time() - t
+    g = api.GradGP(X, y, dY, kernel)
+    lp = g.update(lam, 1.2, 0.05, 0.1)
+    L, z = g.factor()
+    mu, var = g.predict(Xs)
+    print(f"ggp d={d} n={n} N={g.N} M={M} {kernel}: logpdf gpu={lp:.10f} cpu={post.logpdf:.10f} |dL|={np.abs(L - post.L).max():.2e} "
+          f"|dmu|={np.abs(mu - mu_o).max():.2e} |dvar|={np.abs(var - var_o).max():.2e} cpu_s={t_cpu:.1f}", flush=True)
+    g.close()
+
+
+def ggp_timing(d=8, n=4096, M=8192):
+    X, y, dY = grad_problem(d, n)
+    Xs = np.random.default_rng(5).uniform(0, 1, (d, M))
+    t = time.time()
+    g = api.GradGP(X, y, dY, "matern52")
+    print(f"ggp create n={n} N={g.N}: {time.time()-t:.2f} s", flush=True)
+    lam = np.full(d, 0.4)
+    for it in range(3):
+        t = time.time()
+        lp = g.update(lam, 1.2, 1e-3, 1e-2)
+        t_up = time.time() - t
+        print(f"  update {t_up*1e3:.1f} ms ({g.N**3/3/t_up/1e12:.1f} TF)  logpdf {lp:.6e}", flush=True)
+    for it in range(2):
+        t = time.time()
+        mu, var = g.predict(Xs)
+        t_pr = time.time() - t
+        print(f"  predict M={M}: {t_pr*1e3:.1f} ms ({g.N**2*M/t_pr/1e12:.1f} TF)", flush=True)
+    mu_t, var_t = g.predict(X[:, :64])
+    print(f"  interpolation at training points: max|mu-y|={np.abs(mu_t - y[:64]).max():.2e}  max var={var_t.max():.2e}", flush=True)
+    t = time.time()
+    mu1, var1 = g.predict(Xs[:, :1])
+    print(f"  single candidate: {(time.time()-t)*1e3:.1f} ms  |dmu|={abs(mu1[0]-mu[0]):.1e}", flush=True)
+    g.close()
+
+
 if __name__ == "__main__":
     stages = sys.argv[1:] or ["mfma", "parity", "timing"]
     if "mfma" in stages:
@@ -286,6 +340,14 @@ if __name__ == "__main__":
         parity(8, 300, 70, "sqexp")
         parity(8, 1000, 257)
         parity(8, 1000, 257, noise=1e-3)
+    if "ggp" in stages:
+        for kern in ("matern52", "sqexp", "matern32"):
+            ggp_parity(3, 40, 70, kern)
+        ggp_parity(2, 30, 10, "matern52", dup=False)
+        ggp_parity(8, 150, 40, "matern52")
+        ggp_parity(8, 150, 40, "sqexp", dup=True)
+    if "ggp_big" in stages:
+        ggp_timing(n=int(os.environ.get("GGP_N", "1024")))
     if "parity_big" in stages:
         parity(8, 4096, 512)
     if "timing" in stages:

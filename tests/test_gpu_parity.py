@@ -984,3 +984,167 @@ print("ok64")
     env = dict(os.environ, BOSS_FORCE_BN64="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok64" in r.stdout, r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------------------------------
+# GradientGaussianProcess — gradient observations, the n(1+d) augmented system
+# ------------------------------------------------------------------------------------------
+def make_grad(d, n, seed=3):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (d, n))
+    w = np.linspace(1.0, 2.0, d)[:, None]
+    y = np.sin(2 * np.pi * w * X).sum(0) / np.sqrt(d)
+    dY = 2 * np.pi * w * np.cos(2 * np.pi * w * X) / np.sqrt(d)
+    return X, y, dY
+
+
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+@pytest.mark.parametrize("d,n,M,dup", [(1, 1, 3, False), (3, 40, 70, False), (2, 30, 10, True), (8, 150, 40, False), (16, 70, 33, True)])
+def test_gradient_gp_parity(api, O, kernel, d, n, M, dup):
+    """Augmented Gram + factor + logpdf + prediction against the oracle: N_aug below 1024 runs the fused
+    kernel, above it the few-candidates path; `dup` repeats a training point and puts a candidate on one
+    (the entries the reference evaluates at x_j + 1e-8, gradient_gp.jl:148-152,233)."""
+    X, y, dY = make_grad(d, n)
+    if dup and n > 1:
+        X[:, 1] = X[:, 0]
+    Xs = np.asfortranarray(np.random.default_rng(5).uniform(0, 1, (d, M)))
+    Xs[:, 0] = X[:, min(2, n - 1)]
+    lam = np.linspace(0.35, 0.6, d)
+    post = O.gradient_gp_fit(X, y, dY, kernel, lam, 1.2, 0.05, 0.1)
+    mu_o, var_o = O.gradient_gp_mean_and_var(post, Xs)
+    K = post.L @ post.L.T
+    tol = max(1e-9, np.linalg.cond(K) * K.shape[0] * 2.0 ** -53 * 8)
+    g = api.GradGP(X, y, dY, kernel)
+    assert g.N == n * (1 + d)
+    lp = g.update(lam, 1.2, 0.05, 0.1)
+    L, z = g.factor()
+    assert abs(lp - post.logpdf) <= tol * (1 + abs(post.logpdf))
+    assert np.abs(L - post.L).max() <= tol * np.abs(post.L).max()
+    mu, var = g.predict(Xs)
+    assert np.abs(mu - mu_o).max() <= tol * (1 + np.abs(mu_o).max())
+    assert np.abs(var - var_o).max() <= tol * 1.2 ** 2 and var.min() >= 0.0
+    mu1, var1 = g.predict(Xs[:, :1])                          # the reference's one-candidate call pattern
+    assert abs(mu1[0] - mu_o[0]) <= tol * (1 + abs(mu_o[0])) and abs(var1[0] - var_o[0]) <= tol * 1.2 ** 2
+    # a second update on the resident data (what data_loglike does under the fitter)
+    lp2 = g.update(lam * 1.3, 0.9, 0.02, 0.05)
+    assert abs(lp2 - O.gradient_gp_fit(X, y, dY, kernel, lam * 1.3, 0.9, 0.02, 0.05).logpdf) <= tol * 10 * (1 + abs(lp2))
+    g.close()
+
+
+def test_gradient_gp_wide_candidate_tiles(api, O):
+    """The 64-candidates-per-workgroup kernel (M >= 16384) on a gradient posterior equals the 32-wide one."""
+    d, n = 4, 60
+    X, y, dY = make_grad(d, n)
+    Xs = np.asfortranarray(np.random.default_rng(8).uniform(0, 1, (d, 16384 + 37)))
+    g = api.GradGP(X, y, dY, "matern52")
+    g.update(np.full(d, 0.5), 1.0, 0.05, 0.1)
+    mu, var = g.predict(Xs)
+    mu_s, var_s = g.predict(Xs[:, 16000:])
+    assert np.allclose(mu[16000:], mu_s, rtol=0, atol=1e-12) and np.allclose(var[16000:], var_s, rtol=0, atol=1e-12)
+    post = O.gradient_gp_fit(X, y, dY, "matern52", np.full(d, 0.5), 1.0, 0.05, 0.1)
+    mu_o, var_o = O.gradient_gp_mean_and_var(post, Xs[:, :50])
+    assert np.allclose(mu[:50], mu_o, rtol=0, atol=1e-10) and np.allclose(var[:50], var_o, rtol=0, atol=1e-10)
+    g.close()
+
+
+def test_gradient_gp_errors_and_unsupported_entry_points(api, O):
+    d, n = 2, 12
+    X, y, dY = make_grad(d, n)
+    g = api.GradGP(X, y, dY, "matern52")
+    with pytest.raises(api.BossError):
+        g.predict(X)                                          # not fitted yet
+    with pytest.raises(api.BossError):
+        g.update([0.5, -0.1], 1.0, 0.1, 0.1)
+    with pytest.raises(api.BossError):
+        g.update([0.5, 0.5], 1.0, 0.1, -1.0)
+    g.update([0.5, 0.5], 1.0, 0.1, 0.1)
+    for call in (lambda: api.GP.update(g, [0.5, 0.5], 1.0, 0.1), lambda: g.set_y(y), lambda: g.append(X[:, :1], y[:1]),
+                 lambda: g.reserve(100), lambda: g.predict_grad(X), lambda: g.predict_cov(X), lambda: g.loglike_grad(),
+                 lambda: g.predict(X, np.zeros(n)), lambda: api.Track(g, api.Candidates(X))):
+        with pytest.raises(api.BossError):
+            call()
+    mu, var = g.predict(X)                                    # the handle survives the refused calls
+    assert np.isfinite(mu).all() and (var >= 0).all()
+    with pytest.raises(api.BossError):
+        api.GradGP(np.zeros((17, 3)), np.zeros(3), np.zeros((17, 3)))       # x_dim above the supported 16
+    # coincident points without noise: the augmented matrix is singular -> PosDefException, logpdf -Inf
+    Xd = X.copy()
+    Xd[:, 1] = Xd[:, 2] = Xd[:, 0]
+    gd = api.GradGP(Xd, y, dY, "sqexp")
+    with pytest.raises(api.PosDefException):
+        gd.update([0.5, 0.5], 1.0, 0.0, 0.0)
+    gd.close()
+    g.close()
+
+
+def test_gradient_gp_acquisition_and_host_mirror(api, O):
+    """EI × feasibility over gradient posteriors (P = 2 outputs, S = 2 samples) through boss_acq_ei and through the
+    host mirror (HipGradientGaussianProcess + HipBatchAM in its three shard modes); likelihood through data_loglike."""
+    import boss_jl_amd as B
+    rng = np.random.default_rng(31)
+    d, n, M, P, S = 2, 35, 90, 2, 2
+    X = rng.uniform(0, 1, (d, n))
+    Y = np.stack([np.sin(3 * X[0]) * np.cos(2 * X[1]), X[0] - X[1] ** 2])
+    dY = np.stack([np.stack([3 * np.cos(3 * X[0]) * np.cos(2 * X[1]), -2 * np.sin(3 * X[0]) * np.sin(2 * X[1])]),
+                   np.stack([np.ones(n), -2 * X[1]])])                     # P × d × n
+    Xs = np.asfortranarray(rng.uniform(-0.1, 1.1, (d, M)))
+    y_max, coefs = np.array([np.inf, 0.3]), [1.0, 0.2]
+    prm = [B.HipGradientGPParams(rng.uniform(0.4, 0.8, (d, P)), rng.uniform(0.8, 1.4, P), rng.uniform(0.02, 0.06, P),
+                                 rng.uniform(0.05, 0.2, P)) for _ in range(S)]
+    data = B.GradientData(X, Y, dY)
+    model = B.HipGradientGaussianProcess([None] * P, [None] * P, [None] * P, [None] * P)
+    oposts = [[O.gradient_gp_fit(X, Y[i], dY[i], "matern52", p.lengthscales[:, i], p.amplitudes[i], p.noise_std[i],
+                                 p.grad_noise_std[i]) for i in range(P)] for p in prm]
+    b = O.best_so_far(coefs, Y, y_max)
+    mask = O.in_bounds(Xs, np.zeros(d), np.ones(d))
+    want = np.zeros(M)
+    for s in range(S):
+        mom = [O.gradient_gp_mean_and_var(oposts[s][i], Xs) for i in range(P)]
+        mu, var = np.stack([m[0] for m in mom]), np.stack([m[1] for m in mom])
+        want += O.expected_improvement_lin(coefs, mu, var, b) * O.feas_prob(mu, var, y_max)
+    want = np.where(mask, want / S, 0.0)
+    posts = model.model_posterior(prm, data)
+    acq, am, mx = api.acq_ei([[s.gp for s in p.slices] for p in posts], api.Candidates(Xs), coefs, y_max, b, mask)
+    assert np.allclose(acq, want, rtol=0, atol=1e-10) and am == int(np.argmax(want))
+    mu_h, var_h = posts[0].mean_and_var(Xs[:, 3])
+    assert np.allclose(mu_h, [O.gradient_gp_mean_and_var(oposts[0][i], Xs[:, 3])[0][0] for i in range(P)], atol=1e-10)
+    for p in posts:
+        p.close()
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness(coefs)), model, data,
+                         y_max, prm)
+    for mode in ("candidates", "outputs", "samples"):
+        x, val = B.HipBatchAM(points=Xs, shard=mode).maximize_acquisition(prob)
+        assert np.array_equal(x, Xs[:, int(np.argmax(want))]) and abs(val - want.max()) <= 1e-10, mode
+    ll = model.data_loglike(data)
+    assert abs(ll(prm[0]) - sum(o.logpdf for o in oposts[0])) <= 1e-9 * (1 + abs(sum(o.logpdf for o in oposts[0])))
+    assert np.allclose(model.data_loglike_batch(data, prm), [sum(o.logpdf for o in op) for op in oposts], rtol=1e-9)
+    for g in ll.handles:
+        g.close()
+    d2 = data.augment([0.5, 0.5], [0.1, 0.2], [[1.0, 2.0], [3.0, 4.0]])
+    assert d2.X.shape == (d, n + 1) and d2.dY.shape == (P, d, n + 1) and d2.slice(1).dY.shape == (1, d, n + 1)
+
+
+def test_gradient_gp_full_size(api, O):
+    """n = 4096, d = 8: the 36 864-row augmented system (10.9 GB).  The CPU oracle needs minutes
+    for this size, so the check is through properties: the factor reproduces sampled entries of the augmented
+    matrix, the posterior interpolates values at training points, and a candidate slice predicted alone equals
+    the same slice of the 8192-candidate call."""
+    d, n, M = 8, 4096, 8192
+    X, y, dY = make_grad(d, n)
+    Xs = np.asfortranarray(np.random.default_rng(5).uniform(0, 1, (d, M)))
+    lam = np.full(d, 0.4)
+    g = api.GradGP(X, y, dY, "matern52")
+    lp = g.update(lam, 1.2, 1e-3, 1e-2)
+    assert np.isfinite(lp)
+    mu, var = g.predict(Xs)
+    assert np.isfinite(mu).all() and (var >= 0).all() and var.max() <= 1.2 ** 2 * (1 + 1e-12)
+    mu_t, var_t = g.predict(X[:, :64])
+    assert np.abs(mu_t - y[:64]).max() <= 1e-4 and var_t.max() <= 1e-5          # interpolation
+    h = 1e-5                                                                     # ... of the gradients too
+    e = np.zeros((d, 1))
+    e[2] = h
+    dmu = (g.predict(X[:, :64] + e)[0] - g.predict(X[:, :64] - e)[0]) / (2 * h)
+    assert np.abs(dmu - dY[2, :64]).max() <= 1e-2 * np.abs(dY).max()
+    mu_s, var_s = g.predict(Xs[:, 100:133])                                      # few-candidates path vs fused kernel
+    assert np.allclose(mu_s, mu[100:133], rtol=0, atol=1e-9) and np.allclose(var_s, var[100:133], rtol=0, atol=1e-9)
+    g.close()

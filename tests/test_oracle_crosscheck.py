@@ -168,3 +168,96 @@ def test_loglike_gradient_restatement_against_finite_differences(kernel):
         fd = (O.gp_data_loglike_slice(X, y, kernel, tp[:d], tp[d], tp[d + 1], mean=mean) -
               O.gp_data_loglike_slice(X, y, kernel, tm[:d], tm[d], tm[d + 1], mean=mean)) / (2 * eps)
         assert abs(g[k] - fd) <= 1e-5 * (1 + abs(fd)), (k, g[k], fd)
+
+
+# ------------------------------------------------------------------------------------------
+# GradientGaussianProcess restatement: the reference holds no tests or fixtures for
+# this model, so the oracle is pinned by finite differences of the plain kernel and by the
+# properties the construction must have.
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", [O.MATERN32, O.MATERN52, O.SQEXP])
+def test_augmented_kernel_blocks_are_kernel_derivatives(kernel):
+    rng = np.random.default_rng(0)
+    d, n = 3, 6
+    X = rng.uniform(0, 1, (d, n))
+    lam, amp = np.array([0.5, 0.8, 1.1]), 1.3
+    K = O.augmented_kernel_matrix(kernel, X, lam, amp, 0.0, 0.0)
+    amp2, lm = (amp + 1e-8) ** 2, lam + 1e-8
+
+    def k(a, b):
+        return amp2 * float(O.kappa(kernel, np.sqrt(np.sum(((a - b) / lm) ** 2))))
+    h = 1e-5
+    for i in range(n):
+        for j in range(n):
+            assert abs(K[i, j] - k(X[:, i], X[:, j])) <= 1e-14
+            if i == j:
+                continue
+            for l in range(d):
+                e = np.zeros(d)
+                e[l] = h
+                fd = (k(X[:, i], X[:, j] + e) - k(X[:, i], X[:, j] - e)) / (2 * h)
+                assert abs(fd - K[i, n + l * n + j]) <= 1e-8                      # ∂k/∂(x_j)_l
+                for m in range(d):
+                    f = np.zeros(d)
+                    f[m] = h
+                    fd2 = (k(X[:, i] + e, X[:, j] + f) - k(X[:, i] + e, X[:, j] - f) - k(X[:, i] - e, X[:, j] + f)
+                           + k(X[:, i] - e, X[:, j] - f)) / (4 * h * h)
+                    assert abs(fd2 - K[n + l * n + i, n + m * n + j]) <= 5e-6     # ∂²k/∂(x_i)_l∂(x_j)_m
+    assert np.array_equal(K, K.T)                                   # Symmetric(K): the upper triangle mirrored
+    assert np.linalg.eigvalsh(K).min() > 0
+
+
+def test_augmented_cross_cov_matches_the_matrix_columns():
+    """k*(x*) for x* equal to a training point (shifted off the coincidence tolerance) is that point's column of
+    the function block and of the gradient blocks."""
+    rng = np.random.default_rng(1)
+    d, n = 2, 5
+    X = rng.uniform(0, 1, (d, n))
+    lam = np.array([0.6, 0.9])
+    K = O.augmented_kernel_matrix(O.MATERN52, X, lam, 1.0, 0.0, 0.0)
+    xs = X[:, [3]] + 1e-6
+    Kx = O.augmented_kernel_matrix(O.MATERN52, np.hstack([xs, X]), lam, 1.0, 0.0, 0.0)
+    ks = O.augmented_cross_cov(O.MATERN52, X, lam, 1.0, xs)[:, 0]
+    n1 = n + 1
+    want = np.concatenate([Kx[0, 1:n1]] + [Kx[0, n1 + l * n1 + 1:n1 + (l + 1) * n1] for l in range(d)])
+    assert np.allclose(ks, want, rtol=0, atol=1e-14)
+    assert np.allclose(ks, np.concatenate([K[3, :n]] + [K[3, n + l * n:n + (l + 1) * n] for l in range(d)]), atol=1e-4)
+
+
+def test_gradient_gp_interpolates_values_and_gradients():
+    rng = np.random.default_rng(2)
+    d, n = 2, 25
+    X = rng.uniform(0, 1, (d, n))
+    y = np.sin(3 * X[0]) * np.cos(2 * X[1])
+    dY = np.stack([3 * np.cos(3 * X[0]) * np.cos(2 * X[1]), -2 * np.sin(3 * X[0]) * np.sin(2 * X[1])])
+    post = O.gradient_gp_fit(X, y, dY, O.MATERN52, [0.5, 0.5], 1.0, 1e-3, 1e-3)
+    mu, var = O.gradient_gp_mean_and_var(post, X)
+    assert np.allclose(mu, y, atol=1e-4) and var.max() < 1e-5
+    h = 1e-5
+    for l in range(d):
+        e = np.zeros((d, 1))
+        e[l] = h
+        g = (O.gradient_gp_mean_and_var(post, X + e)[0] - O.gradient_gp_mean_and_var(post, X - e)[0]) / (2 * h)
+        assert np.allclose(g, dY[l], atol=5e-3)
+    # gradients carry information: the same data without them predict worse between the points
+    Xt = rng.uniform(0.1, 0.9, (d, 200))
+    truth = np.sin(3 * Xt[0]) * np.cos(2 * Xt[1])
+    plain = O.gp_fit(X, y, O.MATERN52, [0.5, 0.5], 1.0, 1e-3)
+    err_g = np.abs(O.gradient_gp_mean_and_var(post, Xt)[0] - truth).max()
+    err_p = np.abs(O.gp_mean_and_var(plain, Xt)[0] - truth).max()
+    assert err_g < err_p
+
+
+def test_gradient_gp_with_uninformative_gradients_reduces_to_the_plain_gp():
+    rng = np.random.default_rng(3)
+    d, n = 2, 20
+    X = rng.uniform(0, 1, (d, n))
+    y = np.sin(3 * X).sum(0)
+    dY = rng.standard_normal((d, n))
+    lam = np.array([0.4, 0.7])
+    post = O.gradient_gp_fit(X, y, dY, O.MATERN52, lam, 1.1, 0.05, 1e6)
+    plain = O.gp_fit(X, y, O.MATERN52, lam, 1.1, 0.05)
+    Xt = rng.uniform(0, 1, (d, 30))
+    mu_g, var_g = O.gradient_gp_mean_and_var(post, Xt)
+    mu_p, var_p = O.gp_mean_and_var(plain, Xt, clip=False)
+    assert np.allclose(mu_g, mu_p, atol=1e-8) and np.allclose(var_g, var_p, atol=1e-8)
