@@ -251,6 +251,25 @@ def main():
                   "block_cholesky_append_ms": t_app * 1e3,
                   "append_vs_refactorisation": (t_upd / args.steps) / t_app,
                   "posterior_gradient_evals_per_sec": M_CAND / t_grad, "ms_gradient_batch": t_grad * 1e3}
+        # gradient observations (GradientGaussianProcess, §8f4): the n(1+d) = 36 864-row augmented system of the same
+        # N=4096, d=8 data — 10.9 GB resident, 1.67e13 flops per update
+        w = np.linspace(1.0, 2.0, D)[:, None]
+        yg = np.sin(2 * np.pi * w * X).sum(0) / np.sqrt(D)
+        dYg = 2 * np.pi * w * np.cos(2 * np.pi * w * X) / np.sqrt(D)
+        gg = api.GradGP(X, yg, dYg, KERNEL, device=dev)
+        gg.update(np.full(D, 0.4), 1.2, 1e-3, 1e-2)
+        t0 = time.perf_counter()
+        gg.update(np.full(D, 0.41), 1.2, 1e-3, 1e-2)
+        t_gu = time.perf_counter() - t0
+        gg.predict(Xs)
+        t0 = time.perf_counter()
+        gg.predict(Xs)
+        t_gp = time.perf_counter() - t0
+        na = N_OBS * (1 + D)
+        extras["gradient_gp"] = {"n": N_OBS, "d": D, "augmented_rows": na, "ms_update": t_gu * 1e3,
+                                 "update_tflops": na ** 3 / 3 / t_gu / 1e12, "ms_predict_8192": t_gp * 1e3,
+                                 "predict_tflops": float(na) ** 2 * M_CAND / t_gp / 1e12}
+        gg.close()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

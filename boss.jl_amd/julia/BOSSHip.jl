@@ -188,4 +188,33 @@ function loglike_and_grad!(h::Ptr{Cvoid}, λ::Vector{Float64}, α::Float64, σ::
     check(ccall((:boss_gp_loglike_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, C_NULL, g))
     return lp[], g            # g = [∂/∂λ_1 … ∂/∂λ_d, ∂/∂α, ∂/∂σ]; add the priors' gradients and chain through the bijector
 end
+# ---------------------------------------------------------------- GradientGaussianProcess (values + gradients)
+# BOSS.GradientGaussianProcess with the n(1+d) augmented system on the device; data::BOSS.GradientData.
+struct HipGradientGaussianProcess{G<:BOSS.GradientGaussianProcess} <: BOSS.SurrogateModel
+    gp::G
+    device::Cint
+end
+for f in (:params_loglike, :_params_sampler, :vectorizer, :bijector, :param_lengths)
+    @eval BOSS.$f(m::HipGradientGaussianProcess, args...) = BOSS.$f(m.gp, args...)
+end
+sliceable(::HipGradientGaussianProcess) = true
+slice(m::HipGradientGaussianProcess, i::Int) = HipGradientGaussianProcess(slice(m.gp, i), m.device)
+function ggp_create(m::HipGradientGaussianProcess, data::BOSS.GradientData, i::Int)
+    X = Matrix{Float64}(data.X); h = Ref{Ptr{Cvoid}}()
+    dY = ndims(data.dY) == 3 ? Matrix{Float64}(data.dY[i, :, :]) : Matrix{Float64}(data.dY)     # x_dim × n
+    check(ccall((:boss_ggp_create, lib), Cint, (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+          m.device, kernel_id(m.gp.kernel), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]), dY, h))
+    return h[]
+end
+ggp_update(h, p::BOSS.GradientGaussianProcessParams, i::Int) = (lp = Ref{Cdouble}();
+    check(ccall((:boss_ggp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Cdouble, Cint, Ref{Cdouble}),
+          h, Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], p.σ_∂[i], 0, lp)); lp[])
+function model_posterior_slice(m::HipGradientGaussianProcess, p::BOSS.GradientGaussianProcessParams, data::BOSS.GradientData, i::Int)
+    h = ggp_create(m, data, i); ggp_update(h, p, i)
+    return HipPosteriorSlice(h, nothing)          # mean / var / mean_and_var above apply (gradient_gp.jl:334-361)
+end
+function data_loglike(m::HipGradientGaussianProcess, data::BOSS.GradientData)
+    h = ggp_create(m, data, 1)                    # per-output likelihood of the sliced model (gradient_gp.jl:367-397)
+    return p -> try ggp_update(h, p, 1) catch e; e isa PosDefException ? -Inf : rethrow() end
+end
 end # module
