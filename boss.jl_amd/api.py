@@ -34,6 +34,9 @@ SIGNATURES = {
     "boss_gp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_ucp, C.POINTER(C.c_void_p)]),
     "boss_gp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, _c_dp, C.c_int, _c_dp]),
     "boss_gp_sync": (C.c_int, [C.c_void_p, _c_dp]),
+    "boss_ngp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_ucp, C.POINTER(C.c_void_p)]),
+    "boss_ngp_update": (C.c_int, [C.c_void_p, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int, _c_dp]),
+    "boss_ngp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_ggp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_void_p)]),
     "boss_ggp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, C.c_double, C.c_int, _c_dp]),
     "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
@@ -348,6 +351,65 @@ class GradGP(GP):
             self.logpdf = out.value
             return out.value
         return None
+
+
+class GibbsGP(GP):
+    """One output slice's posterior under the NonstationaryGP's Gibbs kernel (nonstationary_gp.jl:61-107): the
+    latent λ(·), α(·), σ(·) are evaluated by the caller and passed as arrays."""
+
+    def __init__(self, X, y, discrete=None, device: int = 0):
+        lib = load_library()
+        X = _f64(X, 2)
+        y = _f64(np.asarray(y).reshape(-1), 1)
+        self.d, self.N = X.shape
+        if y.shape[0] != self.N:
+            raise ValueError("y must have one entry per column of X")
+        self.device = device
+        self.kernel = None
+        disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
+        h = C.c_void_p()
+        _check(lib.boss_ngp_create(device, self.d, self.N, _dp(X), _dp(y), _ucp(disc), C.byref(h)))
+        self._h = h
+        self.logpdf = None
+
+    def update(self, lam_X, amp_X, noise_X, mean_X=None, sync: bool = True) -> Optional[float]:
+        lam = _f64(lam_X, 2)
+        amp = _f64(np.asarray(amp_X).reshape(-1), 1)
+        noi = _f64(np.asarray(noise_X).reshape(-1), 1)
+        if lam.shape != (self.d, self.N) or amp.shape[0] != self.N or noi.shape[0] != self.N:
+            raise ValueError("lam_X must be d×N, amp_X and noise_X length N")
+        m = None if mean_X is None else _f64(np.asarray(mean_X).reshape(-1), 1)
+        if m is not None and m.shape[0] != self.N:
+            raise ValueError("mean_X must have N entries")
+        out = C.c_double(0.0)
+        _check(load_library().boss_ngp_update(self._h, _dp(lam), _dp(amp), _dp(noi), _dp(m), 0 if sync else FIT_NO_SYNC,
+                                              C.byref(out)))
+        if sync:
+            self.logpdf = out.value
+            return out.value
+        return None
+
+    def predict(self, Xs, lam_Xs, amp_Xs, mean_Xs=None):
+        """mean_and_var with _clip_var; lam_Xs d×M and amp_Xs M are λ(x*), α(x*)."""
+        Xs = _f64(Xs)
+        if Xs.ndim == 1:
+            Xs = _f64(Xs.reshape(-1, 1))
+        M = Xs.shape[1]
+        lam = _f64(np.asarray(lam_Xs, dtype=np.float64).reshape(self.d, M), 2)
+        amp = _f64(np.asarray(amp_Xs).reshape(-1), 1)
+        if Xs.shape[0] != self.d or amp.shape[0] != M:
+            raise ValueError("candidates must be d×M with lam_Xs d×M and amp_Xs M")
+        ms = None if mean_Xs is None else _f64(np.asarray(mean_Xs).reshape(-1), 1)
+        mu = np.zeros(M)
+        var = np.zeros(M)
+        bad = C.c_long(-1)
+        rc = load_library().boss_ngp_predict(self._h, M, _dp(Xs), _dp(lam), _dp(amp), _dp(ms), _dp(mu), _dp(var), C.byref(bad))
+        if rc == BOSS_E_NEG_VAR:
+            e = DomainError(rc, load_library().boss_last_error().decode())
+            e.bad_index = bad.value
+            raise e
+        _check(rc)
+        return mu, var
 
 
 class Candidates:

@@ -183,6 +183,10 @@ struct boss_gp {
     // Xraw is [d][ldx]; hyp = {α², σ², σ_∂²}
     bool aug = false;
     int npts = 0, ldx = 0;
+    // nonstationary posterior (NonstationaryGP, Gibbs kernel): per-point λ [d][Np], α [Np], σ [Np]; Xraw holds the
+    // (rounded where discrete) training points
+    bool gibbs = false;
+    double *lamX = nullptr, *ampX = nullptr, *noiseX = nullptr;
 };
 
 struct boss_cand {
@@ -405,6 +409,9 @@ static void gp_release(boss_gp* g) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_res) (void)hipHostFree(g->host_res);
+    if (g->lamX) (void)hipFree(g->lamX);
+    if (g->ampX) (void)hipFree(g->ampX);
+    if (g->noiseX) (void)hipFree(g->noiseX);
     if (g->host_par) (void)hipHostFree(g->host_par);
     if (g->par_ev) (void)hipEventDestroy(g->par_ev);
     if (g->dinv_ev) (void)hipEventDestroy(g->dinv_ev);
@@ -523,11 +530,32 @@ extern "C" int boss_ggp_create(int device, int kernel, int d, int n, const doubl
 #define NOT_FOR_AUG(g)                                                                                            \
     do {                                                                                                          \
         if ((g)->aug) return fail(BOSS_E_INVALID, "not available for gradient-observation posteriors (boss_ggp_*)"); \
+        if ((g)->gibbs) return fail(BOSS_E_INVALID, "not available for nonstationary posteriors (boss_ngp_*)");      \
     } while (0)
+
+// NonstationaryGP (src/models/nonstationary_gp/nonstationary_gp.jl): the data of one output slice; the
+// per-point hyper-parameters arrive with boss_ngp_update.
+extern "C" int boss_ngp_create(int device, int d, int N, const double* X, const double* y, const unsigned char* discrete,
+                               boss_gp_t** out) {
+    int rc = gp_create_common(device, KERN_SQEXP, d, N, N, X, y, discrete, false, out);
+    if (rc) return rc;
+    boss_gp* g = *out;
+    g->gibbs = true;
+    g->kernel = KERN_GIBBS;
+    const size_t Np = g->Np;
+    if (hipMalloc((void**)&g->lamX, sizeof(double) * d * Np) != hipSuccess ||
+        hipMalloc((void**)&g->ampX, sizeof(double) * Np) != hipSuccess ||
+        hipMalloc((void**)&g->noiseX, sizeof(double) * Np) != hipSuccess) {
+        gp_release(g);
+        *out = nullptr;
+        return fail(BOSS_E_ALLOC, "device allocation failed");
+    }
+    return BOSS_OK;
+}
 
 extern "C" int boss_gp_set_y(boss_gp_t* g, const double* y) {
     if (!g || !y) return fail(BOSS_E_INVALID, "NULL argument");
-    NOT_FOR_AUG(g);
+    if (g->aug) return fail(BOSS_E_INVALID, "not available for gradient-observation posteriors (boss_ggp_*)");
     HIPCHK(hipSetDevice(g->ctx->device));
     HIPCHK(hipMemcpyAsync(g->y, y, sizeof(double) * g->N, hipMemcpyHostToDevice, g->ctx->stream));
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
@@ -609,7 +637,7 @@ static int factor_enqueue(boss_gp* g) {
     HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
     {
         ProfScope ps(c, "prep");
-        if (!g->aug)
+        if (!g->aug && !g->gibbs)
             hipLaunchKernelGGL(scale_points_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc,
                                (size_t)0, g->invlam, g->d, g->Np);
         hipLaunchKernelGGL(rhs_rows_kernel, dim3((g->Np + 255) / 256, 1, 1), dim3(256), 0, s, g->A, g->ld, (size_t)0,
@@ -620,6 +648,11 @@ static int factor_enqueue(boss_gp* g) {
         const long long t64 = g->Np / 64;
         hipLaunchKernelGGL(aug_gram_kernel, dim3((unsigned)(t64 * (t64 + 1) / 2)), dim3(256), 0, s, (const double*)g->Xraw, g->ldx,
                            g->d, g->npts, g->N, g->Np, g->kernel, (const double*)g->hyp, (const double*)g->invlam, g->A, g->ld);
+    } else if (g->gibbs) {
+        ProfScope ps(c, "gram");
+        const int t64 = g->Np / 64;
+        hipLaunchKernelGGL(gibbs_gram_kernel, dim3(t64 * (t64 + 1) / 2), dim3(256), 0, s, (const double*)g->Xraw,
+                           (const double*)g->lamX, (const double*)g->ampX, (const double*)g->noiseX, g->d, g->N, g->Np, g->A, g->ld);
     } else {
         gram_enqueue(c, g->Xsc, 0, g->d, g->N, g->Np, g->kernel, g->hyp, g->A, g->ld, 0, 1);
     }
@@ -706,6 +739,51 @@ extern "C" int boss_ggp_update(boss_gp_t* g, const double* lengthscale, double a
     HIPCHK(hipMemcpyAsync(g->hyp, hyp, 3 * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(g->par_ev, s));
     rc = factor_enqueue(g);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    g->pending = true;
+    if (flags & BOSS_FIT_NO_SYNC) return BOSS_OK;
+    return gp_finish(g, logpdf_out);
+}
+
+// finite_nongp + logpdf / posterior (nonstationary_gp.jl:153-196, :237-245): the caller evaluates its latent
+// models at the training points — lam_X d×N (column j = λ(x_j)), amp_X N, noise_X N.
+extern "C" int boss_ngp_update(boss_gp_t* g, const double* lam_X, const double* amp_X, const double* noise_X,
+                               const double* mean_X, int flags, double* logpdf_out) {
+    if (!g || !lam_X || !amp_X || !noise_X) return fail(BOSS_E_INVALID, "NULL argument");
+    if (!g->gibbs) return fail(BOSS_E_INVALID, "handle was not created by boss_ngp_create");
+    const int d = g->d, N = g->N, Np = g->Np;
+    std::vector<double> lam((size_t)d * Np, 1.0), amp(Np, 0.0), noi(Np, 0.0);
+    for (int j = 0; j < N; ++j) {
+        for (int k = 0; k < d; ++k) {
+            const double v = lam_X[(size_t)j * d + k];
+            if (!(v > 0.0) || !std::isfinite(v)) return fail(BOSS_E_INVALID, "lengthscales must be finite and > 0");
+            lam[(size_t)k * Np + j] = v;
+        }
+        if (!(amp_X[j] >= 0.0) || !std::isfinite(amp_X[j])) return fail(BOSS_E_INVALID, "amplitudes must be finite and >= 0");
+        if (!(noise_X[j] >= 0.0) || !std::isfinite(noise_X[j])) return fail(BOSS_E_INVALID, "noise stds must be finite and >= 0");
+        amp[j] = amp_X[j];
+        noi[j] = noise_X[j];
+    }
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    hipStream_t s = c->stream;
+    g->fitted = false;
+    g->have_dinv = false;
+    ++g->epoch;
+    HIPCHK(hipMemcpyAsync(g->lamX, lam.data(), sizeof(double) * d * Np, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->ampX, amp.data(), sizeof(double) * Np, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->noiseX, noi.data(), sizeof(double) * Np, hipMemcpyHostToDevice, s));
+    if (mean_X) {
+        HIPCHK(hipMemcpyAsync(g->mean, mean_X, sizeof(double) * N, hipMemcpyHostToDevice, s));
+        g->has_mean = true;
+    } else if (g->has_mean) {
+        HIPCHK(hipMemsetAsync(g->mean, 0, sizeof(double) * Np, s));
+        g->has_mean = false;
+    }
+    HIPCHK(hipStreamSynchronize(s));                         // the staging vectors go out of scope
+    int rc = factor_enqueue(g);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     g->pending = true;
@@ -1099,10 +1177,12 @@ __global__ void scale_cand_kernel(const double* __restrict__ Craw, double* __res
 
 // enqueue μ/σ² (unclipped) of one posterior at resident candidates into device arrays mu, var (length ≥ M)
 static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_dev, double* mu, double* var,
-                           bool for_grad = false) {
+                           bool for_grad = false, const double* clam_dev = nullptr, const double* camp_dev = nullptr) {
     Ctx* c = g->ctx;
     hipStream_t s = c->stream;
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    if (g->gibbs && !clam_dev)
+        return fail(BOSS_E_INVALID, "nonstationary posteriors predict through boss_ngp_predict (λ(x*), α(x*) are needed)");
     if (cd->ctx != c) return fail(BOSS_E_INVALID, "candidates and posterior live on different devices");
     if (cd->d != g->d) return fail(BOSS_E_INVALID, "candidate dimension differs from the model's x_dim");
     dinv_join(g);
@@ -1122,8 +1202,9 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     rc = ws_reserve(c->vscratch, sizeof(double) * (size_t)tiles * BN * g->Np);
     if (rc) return rc;
     double* Csc = (double*)c->csc.p;
-    hipLaunchKernelGGL(scale_cand_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, cd->Craw, Csc, g->invlam,
-                       g->discrete_dev, g->d, Mp);
+    if (!g->gibbs)
+        hipLaunchKernelGGL(scale_cand_kernel, dim3((Mp + 255) / 256), dim3(256), 0, s, cd->Craw, Csc, g->invlam,
+                           g->discrete_dev, g->d, Mp);
     const int dbg = getenv("BOSS_DBG") ? atoi(getenv("BOSS_DBG")) : 0;
     static const bool no_few = getenv("BOSS_NO_FEW") && atoi(getenv("BOSS_NO_FEW"));
     static const int few_max_tiles = getenv("BOSS_FEW_MAX_TILES") ? atoi(getenv("BOSS_FEW_MAX_TILES")) : 128;
@@ -1146,26 +1227,40 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
             hipLaunchKernelGGL(aug_kstar_kernel, dim3(g->Np / 256, ftiles), dim3(256), aug_lds, s, (const double*)g->Xraw, g->ldx,
                                g->d, g->npts, g->N, g->Np, (const double*)cd->Craw, Mp, g->kernel, g->amp2,
                                (const double*)g->invlam, R, 32);
+        else if (g->gibbs)
+            hipLaunchKernelGGL(gibbs_kstar_kernel<32>, dim3(g->Np / 256, ftiles), dim3(256), sizeof(double) * (2 * g->d + 1) * 32, s,
+                               (const double*)g->Xraw, (const double*)g->lamX, (const double*)g->ampX, g->d, g->N, g->Np,
+                               (const double*)cd->Craw, clam_dev, camp_dev, Mp, R);
         else
             hipLaunchKernelGGL(kstar_rows_kernel, dim3(g->Np / 256, ftiles), dim3(256), sizeof(double) * g->d * 32, s,
                                (const double*)g->Xsc, g->Np, g->N, (const double*)Csc, g->d, Mp, g->kernel, g->amp2, R);
         for (int ib = 0; ib < nb; ++ib) {
             hipLaunchKernelGGL(few_finish_kernel<G>, dim3(ftiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->A,
                                g->ld, g->Np, ib, (const double*)R, (const double*)g->Dinv2, V, ssmz, ib == nb - 1 ? 1 : 0,
-                               mean_s_dev, cd->M, g->amp2, mu, var, g->aug ? 1 : 0);
+                               mean_s_dev, cd->M, g->amp2, mu, var, g->aug ? 1 : g->gibbs ? 2 : 0);
             const int nupd = (nb - 1 - ib) * (PRED_RB / BLK);
             if (nupd > 0)
                 hipLaunchKernelGGL(few_update_kernel<GU>, dim3(nupd, ftiles), dim3(GU::NTHREADS), 0, s, (const double*)g->A, g->ld,
                                    g->Np, ib, (const double*)V, R);
         }
+        if (g->gibbs) hipLaunchKernelGGL(gibbs_var_kernel, dim3((cd->M + 255) / 256), dim3(256), 0, s, var, camp_dev, cd->M);
         HIPCHK(hipGetLastError());
         return BOSS_OK;
     }
-    if (g->aug) {
+    if (g->aug || g->gibbs) {
         ProfScope ps(c, "predict");
         double* V = (double*)c->vscratch.p;
-        hipLaunchKernelGGL(aug_kstar_kernel, dim3(g->Np / 256, tiles), dim3(256), aug_lds, s, (const double*)g->Xraw, g->ldx, g->d,
-                           g->npts, g->N, g->Np, (const double*)cd->Craw, Mp, g->kernel, g->amp2, (const double*)g->invlam, V, BN);
+        if (g->aug)
+            hipLaunchKernelGGL(aug_kstar_kernel, dim3(g->Np / 256, tiles), dim3(256), aug_lds, s, (const double*)g->Xraw, g->ldx, g->d,
+                               g->npts, g->N, g->Np, (const double*)cd->Craw, Mp, g->kernel, g->amp2, (const double*)g->invlam, V, BN);
+        else if (BN == 32)
+            hipLaunchKernelGGL(gibbs_kstar_kernel<32>, dim3(g->Np / 256, tiles), dim3(256), sizeof(double) * (2 * g->d + 1) * 32, s,
+                               (const double*)g->Xraw, (const double*)g->lamX, (const double*)g->ampX, g->d, g->N, g->Np,
+                               (const double*)cd->Craw, clam_dev, camp_dev, Mp, V);
+        else
+            hipLaunchKernelGGL(gibbs_kstar_kernel<64>, dim3(g->Np / 256, tiles), dim3(256), sizeof(double) * (2 * g->d + 1) * 64, s,
+                               (const double*)g->Xraw, (const double*)g->lamX, (const double*)g->ampX, g->d, g->N, g->Np,
+                               (const double*)cd->Craw, clam_dev, camp_dev, Mp, V);
         if (BN == 32) {
             typedef PredG32 G;
             hipLaunchKernelGGL((predict_kernel<G, true>), dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
@@ -1175,6 +1270,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
             hipLaunchKernelGGL((predict_kernel<G, true>), dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, g->A, g->ld, g->Np,
                                g->N, g->Dinv, g->Xsc, Csc, g->d, Mp, g->kernel, g->amp2, V, mean_s_dev, cd->M, mu, var, dbg);
         }
+        if (g->gibbs) hipLaunchKernelGGL(gibbs_var_kernel, dim3((cd->M + 255) / 256), dim3(256), 0, s, var, camp_dev, cd->M);
         HIPCHK(hipGetLastError());
         return BOSS_OK;
     }
@@ -1231,6 +1327,76 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
     (void)hipMemcpyAsync(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
     cleanup();
+    if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
+    if (bad != ~0ULL) {
+        if (bad_index) *bad_index = (long)bad;
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "The posterior GP predicted variance %g but only values above -1e-08 are tolerated. (DomainError)", var[bad]);
+        return fail(BOSS_E_NEG_VAR, msg);
+    }
+    return BOSS_OK;
+}
+
+// mean_and_var of a NonstationaryGP posterior (GaussianProcessPosterior over the Gibbs kernel,
+// nonstationary_gp.jl:153-157 -> gaussian_process.jl:143-194): lam_Xs d×M and amp_Xs M are the caller's latent
+// models at the candidates (evaluated at the ROUNDED candidate where dims are discrete, as DiscreteKernel does).
+extern "C" int boss_ngp_predict(boss_gp_t* g, int M, const double* Xs, const double* lam_Xs, const double* amp_Xs,
+                                const double* mean_Xs, double* mu, double* var, long* bad_index) {
+    if (!g || !Xs || !lam_Xs || !amp_Xs || !mu || !var) return fail(BOSS_E_INVALID, "NULL argument");
+    if (!g->gibbs) return fail(BOSS_E_INVALID, "handle was not created by boss_ngp_create");
+    if (M < 1) return fail(BOSS_E_INVALID, "M must be >= 1");
+    if (bad_index) *bad_index = -1;
+    if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
+    const int d = g->d, Mp = round_up(M, 64);
+    std::vector<double> buf, lam((size_t)d * Mp, 1.0), amp(Mp, 0.0);
+    pack_points(buf, Xs, d, M, Mp, g->discrete.empty() ? nullptr : g->discrete.data());
+    for (int j = 0; j < M; ++j) {
+        for (int k = 0; k < d; ++k) {
+            const double v = lam_Xs[(size_t)j * d + k];
+            if (!(v > 0.0) || !std::isfinite(v)) return fail(BOSS_E_INVALID, "lengthscales must be finite and > 0");
+            lam[(size_t)k * Mp + j] = v;
+        }
+        if (!(amp_Xs[j] >= 0.0) || !std::isfinite(amp_Xs[j])) return fail(BOSS_E_INVALID, "amplitudes must be finite and >= 0");
+        amp[j] = amp_Xs[j];
+    }
+    Ctx* c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    hipStream_t s = c->stream;
+    int rc = ws_reserve(c->craw, sizeof(double) * ((size_t)2 * d * Mp + Mp));
+    if (rc) return rc;
+    boss_cand cd;
+    cd.ctx = c;
+    cd.d = d;
+    cd.M = M;
+    cd.Mp = Mp;
+    cd.Craw = (double*)c->craw.p;
+    double* clam = cd.Craw + (size_t)d * Mp;
+    double* camp = clam + (size_t)d * Mp;
+    HIPCHK(hipMemcpyAsync(cd.Craw, buf.data(), sizeof(double) * d * Mp, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(clam, lam.data(), sizeof(double) * d * Mp, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(camp, amp.data(), sizeof(double) * Mp, hipMemcpyHostToDevice, s));
+    rc = ws_reserve(c->pred, sizeof(double) * (3 * (size_t)M + 2));   // mu | var | mean | bad
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    double* dev = (double*)c->pred.p;
+    double *dmu = dev, *dvar = dev + M, *dmean = dev + 2 * (size_t)M;
+    unsigned long long* dbad = (unsigned long long*)(dev + 3 * (size_t)M);
+    if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * M, hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(dbad, 0xff, sizeof(unsigned long long), s);
+    rc = predict_enqueue(g, &cd, mean_Xs ? dmean : nullptr, dmu, dvar, false, clam, camp);
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    hipLaunchKernelGGL(clip_var_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dvar, M, dbad);
+    unsigned long long bad = 0;
+    (void)hipMemcpyAsync(mu, dmu, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(var, dvar, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
     if (bad != ~0ULL) {
         if (bad_index) *bad_index = (long)bad;

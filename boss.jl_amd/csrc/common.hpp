@@ -12,6 +12,7 @@ constexpr int BLK = 128;          // block size of the blocked Cholesky / triang
 constexpr int PRED_RB = 256;      // rows per prediction (forward-substitution) step; handles pad N to a multiple of it
 constexpr int RHS_ROWS = 128;     // extra row block carrying (y-m)^T through the factorisation
 constexpr int KERN_MATERN32 = 0, KERN_MATERN52 = 1, KERN_SQEXP = 2;
+constexpr int KERN_GIBBS = 3;               // internal: NonstationaryKernel (nonstationary_gp.jl:61-107), per-point λ and α
 constexpr double MIN_PARAM_VALUE = 1e-8;   // src/models/gaussian_process.jl:5
 constexpr double MAX_NEG_VAR = 1e-8;       // src/models/gaussian_process.jl:13
 constexpr double PREDICT_JITTER = 1e-18;   // AbstractGPs default Σy of post(X*)

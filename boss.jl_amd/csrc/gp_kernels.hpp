@@ -191,6 +191,114 @@ __global__ __launch_bounds__(256) void aug_kstar_kernel(const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// NonstationaryGP (src/models/nonstationary_gp/nonstationary_gp.jl:61-107): the Gibbs kernel
+//   k(x, y) = ((α(x) + α(y))/2)² Π_i sqrt(2 λ_i(x) λ_i(y) / (λ_i(x)² + λ_i(y)²)) exp(−(x_i − y_i)² / (λ_i(x)² + λ_i(y)²))
+// with per-point noise σ(x)² on the diagonal (finite_nongp, :183-196).  λ(·), α(·), σ(·) are the caller's
+// latent models evaluated at the training points / candidates; they cross the ABI as arrays.
+// Points raw (rounded where discrete), P[k*ldp + j]; Lam likewise.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gibbs_dim(double x, double lx, double y, double ly, double& prod, double& esum) {
+    const double q = rcp_refined(__builtin_fma(lx, lx, ly * ly));
+    const double df = x - y;
+    prod *= 2.0 * lx * ly * q;
+    esum = __builtin_fma(df * df, q, esum);
+}
+
+__global__ __launch_bounds__(256) void gibbs_gram_kernel(const double* __restrict__ X, const double* __restrict__ Lam,
+                                                         const double* __restrict__ amp, const double* __restrict__ noise,
+                                                         int d, int N, int Np, double* __restrict__ A, int ld) {
+    __shared__ double xj[16][64], lj[16][64];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const int r = tid & 63, cg = tid >> 6;
+    const int i = bi * 64 + r;
+    double pr[16], es[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        pr[c] = 1.0;
+        es[c] = 0.0;
+    }
+    for (int k0 = 0; k0 < d; k0 += 16) {
+        const int kc = (d - k0 < 16) ? (d - k0) : 16;
+        __syncthreads();
+        for (int idx = tid; idx < kc * 64; idx += 256) {
+            xj[idx >> 6][idx & 63] = X[(size_t)(k0 + (idx >> 6)) * Np + bj * 64 + (idx & 63)];
+            lj[idx >> 6][idx & 63] = Lam[(size_t)(k0 + (idx >> 6)) * Np + bj * 64 + (idx & 63)];
+        }
+        __syncthreads();
+        for (int kk = 0; kk < kc; ++kk) {
+            const double xi = X[(size_t)(k0 + kk) * Np + i], li = Lam[(size_t)(k0 + kk) * Np + i];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) gibbs_dim(xi, li, xj[kk][cg * 16 + c], lj[kk][cg * 16 + c], pr[c], es[c]);
+        }
+    }
+    const double ai = amp[i];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = bj * 64 + cg * 16 + c;
+        if (i < j) continue;
+        double v;
+        if (i < N && j < N) {
+            const double am = 0.5 * (ai + amp[j]);
+            v = am * am * sqrt(pr[c]) * exp(-es[c]);
+            if (i == j) v = __builtin_fma(noise[i], noise[i], v);
+        } else {
+            v = (i == j) ? 1.0 : 0.0;
+        }
+        A[(size_t)j * ld + i] = v;
+    }
+}
+
+// K* of the Gibbs kernel, written where the substitution kernels take their right-hand side
+// (out[tile][row][BN], see aug_kstar_kernel).  One training point per thread.
+template <int BN>
+__global__ __launch_bounds__(256) void gibbs_kstar_kernel(const double* __restrict__ X, const double* __restrict__ Lam,
+                                                          const double* __restrict__ amp, int d, int N, int Np,
+                                                          const double* __restrict__ C, const double* __restrict__ Clam,
+                                                          const double* __restrict__ Camp, int Mp, double* __restrict__ out) {
+    extern __shared__ double sm[];                           // cx[d][BN] | cl[d][BN] | ca[BN]
+    double* cx = sm;
+    double* cl = cx + d * BN;
+    double* ca = cl + d * BN;
+    const int tid = threadIdx.x, c0 = blockIdx.y * BN;
+    out += (size_t)blockIdx.y * Np * BN;
+    for (int idx = tid; idx < d * BN; idx += 256) {
+        cx[idx] = C[(size_t)(idx / BN) * Mp + c0 + (idx % BN)];
+        cl[idx] = Clam[(size_t)(idx / BN) * Mp + c0 + (idx % BN)];
+    }
+    if (tid < BN) ca[tid] = Camp[c0 + tid];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + tid;
+    double pr[BN], es[BN];
+#pragma unroll
+    for (int c = 0; c < BN; ++c) {
+        pr[c] = 1.0;
+        es[c] = 0.0;
+    }
+    for (int k = 0; k < d; ++k) {
+        const double xr = X[(size_t)k * Np + row], lr = Lam[(size_t)k * Np + row];
+#pragma unroll
+        for (int c = 0; c < BN; ++c) gibbs_dim(cx[k * BN + c], cl[k * BN + c], xr, lr, pr[c], es[c]);
+    }
+    const double ar = amp[row];
+    const bool live = row < N;
+#pragma unroll
+    for (int c = 0; c < BN; ++c) {
+        const double am = 0.5 * (ar + ca[c]);
+        out[(size_t)row * BN + c] = live ? am * am * sqrt(pr[c]) * exp(-es[c]) : 0.0;
+    }
+}
+
+// σ²(x*) = k(x*,x*) − Σv² + 1e-18 with k(x*,x*) = α(x*)²; the substitution kernels left −Σv² in var.
+__global__ void gibbs_var_kernel(double* __restrict__ var, const double* __restrict__ Camp, int M) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < M) var[j] = __builtin_fma(Camp[j], Camp[j], var[j]) + PREDICT_JITTER;
+}
+
+// ------------------------------------------------------------------------------------------
 // K4-K7 fused prediction.  One workgroup owns BN candidates and walks the row blocks of L:
 //     R_i = K*_i − Σ_{j<i} L_ij V_j          (MFMA GEMM, V_j re-read from its own scratch slab)
 //     V_i = Dinv_i · R_i                      (MFMA GEMM, R_i resident in LDS)
@@ -351,7 +459,8 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
         const int j = c0 + tid;
         if (j < M) {
             mu_out[j] = (mean_s ? mean_s[j] : 0.0) + z;
-            if constexpr (PRE) var_out[j] = fmax(0.0, amp2 - s);           // gradient_gp.jl:346: no jitter, clamped at 0
+            if constexpr (PRE) var_out[j] = (kern == KERN_GIBBS) ? -s       // per-candidate prior variance: gibbs_var_kernel
+                                                                 : fmax(0.0, amp2 - s);   // gradient_gp.jl:346: no jitter, clamped at 0
             else var_out[j] = amp2 - s + PREDICT_JITTER;
         }
     }
@@ -502,7 +611,7 @@ __global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* _
         ssmz[BN + tid] = z;
         if (last && c0 + tid < M) {
             mu_out[c0 + tid] = (mean_s ? mean_s[c0 + tid] : 0.0) + z;
-            var_out[c0 + tid] = aug ? fmax(0.0, amp2 - s) : amp2 - s + PREDICT_JITTER;
+            var_out[c0 + tid] = aug == 2 ? -s : aug ? fmax(0.0, amp2 - s) : amp2 - s + PREDICT_JITTER;
         }
     }
 }

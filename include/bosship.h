@@ -144,6 +144,27 @@ int boss_ggp_create(int device, int kernel, int d, int n, const double* X, const
 int boss_ggp_update(boss_gp_t* gp, const double* lengthscale, double amplitude, double noise_std,
                     double grad_noise_std, int flags, double* logpdf_out);
 
+/* ---- nonstationary posteriors -----------------------------------------------------
+ * Replaces: NonstationaryGP — NonstationaryKernel / gibbs_kernel (src/models/nonstationary_gp/nonstationary_gp.jl:61-107),
+ *           finite_nongp (:153-196), model_posterior_slice (:153-157), data_loglike_slice (:237-245).
+ *
+ *   k(x, y) = ((a(x) + a(y))/2)^2 prod_i sqrt(2 l_i(x) l_i(y) / (l_i(x)^2 + l_i(y)^2)) exp(-(x_i - y_i)^2 / (l_i(x)^2 + l_i(y)^2)),
+ *   noise s(x_j)^2 on the diagonal.  l(.), a(.), s(.) are the caller's latent models (ParametrizedGP posteriors or
+ *   constants, _param_posterior_slice :198-212) evaluated on the host; they cross the ABI as arrays:
+ *   lam_X d×N (column j = l(x_j)), amp_X N, noise_X N;  lam_Xs d×M, amp_Xs M at the candidates.
+ *   Dims flagged discrete are rounded in both kernel arguments (make_discrete, :183-191); the latent models must
+ *   then be evaluated at the rounded points as well.  No 1e-8 is added to these parameters (the reference adds none).
+ * boss_ngp_update factorises and returns logpdf(FiniteGP, y); boss_ngp_predict is mean_and_var with _clip_var
+ * (k(x*,x*) = a(x*)^2, +1e-18 jitter as for the plain model).  boss_gp_sync, boss_gp_set_y, boss_gp_get_factor,
+ * boss_gp_free and boss_acq_ei_moments (EI on the predicted moments) work with these handles; the other
+ * boss_gp_* / boss_acq_* / boss_track_* entry points return BOSS_E_INVALID for them. */
+int boss_ngp_create(int device, int d, int N, const double* X, const double* y, const unsigned char* discrete,
+                    boss_gp_t** out);
+int boss_ngp_update(boss_gp_t* gp, const double* lam_X, const double* amp_X, const double* noise_X,
+                    const double* mean_X, int flags, double* logpdf_out);
+int boss_ngp_predict(boss_gp_t* gp, int M, const double* Xs, const double* lam_Xs, const double* amp_Xs,
+                     const double* mean_Xs, double* mu, double* var, long* bad_index);
+
 /* ---- batched log-likelihood -----------------------------------------------------------
  * Replaces: the `loglike.(samples)` loop of SamplingMAP (src/model_fitters/sampling.jl:59-78) and the
  * per-sample likelihood calls of OptimizationMAP / TuringBI (src/model_fitters/optimization.jl:153-160,

@@ -716,3 +716,67 @@ def gradient_gp_mean_and_var(post: GradientGPPosterior, Xs):
     V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
     amp2 = (post.amplitude + MIN_PARAM_VALUE) ** 2
     return mu, np.maximum(0.0, amp2 - np.sum(V * V, axis=0))
+
+
+# ------------------------------------------------------------------------------------------
+# NonstationaryGP: src/models/nonstationary_gp/nonstationary_gp.jl.  λ(·), α(·), σ(·) are
+# functions of the input (posteriors of latent ParametrizedGPs, or constants, :198-212); here they arrive
+# evaluated: lam_X d×N, amp_X N, noise_X N at the training points, lam_Xs d×M, amp_Xs M at the candidates.
+# The reference's tests hold nothing for this model.  Pin: with constant λ, α, σ the Gibbs kernel IS the
+# squared-exponential ARD kernel, so the restatement must reproduce the (pinned) plain-GP oracle there
+# (tests/test_oracle_crosscheck.py); with varying parameters PARITY IS UNPINNED.
+# ------------------------------------------------------------------------------------------
+def gibbs_kernel_matrix(Xa, lam_a, amp_a, Xb, lam_b, amp_b):
+    """nonstat_kernel / gibbs_kernel (:66-107):
+    k(x, y) = ((α(x)+α(y))/2)² Π_i sqrt(2 λ_i(x) λ_i(y) / (λ_i(x)² + λ_i(y)²)) exp(−(x_i − y_i)² / (λ_i(x)² + λ_i(y)²))."""
+    Xa, Xb = np.asarray(Xa, np.float64), np.asarray(Xb, np.float64)
+    la, lb = np.asarray(lam_a, np.float64), np.asarray(lam_b, np.float64)
+    K = (0.5 * (np.asarray(amp_a, np.float64)[:, None] + np.asarray(amp_b, np.float64)[None, :])) ** 2
+    for i in range(Xa.shape[0]):                                       # the per-dimension product of :93-99
+        s = la[i][:, None] ** 2 + lb[i][None, :] ** 2
+        K = K * (np.sqrt(2.0 * la[i][:, None] * lb[i][None, :] / s) * np.exp(-((Xa[i][:, None] - Xb[i][None, :]) ** 2) / s))
+    return K
+
+
+@dataclass
+class NonstationaryPosterior:
+    X: np.ndarray
+    lam_X: np.ndarray
+    amp_X: np.ndarray
+    discrete: Optional[np.ndarray]
+    L: np.ndarray
+    a: np.ndarray
+    logpdf: float
+
+
+def nonstationary_fit(X, y, lam_X, amp_X, noise_X, mean=None, discrete=None) -> NonstationaryPosterior:
+    """finite_nongp (:183-196) + AbstractGPs.posterior / logpdf (:153-157, :237-245): K = Gibbs Gram matrix of the
+    (rounded where discrete) points + diag(σ(x_j)²)."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    N = X.shape[1]
+    Xr = discrete_round(X, discrete)
+    K = gibbs_kernel_matrix(Xr, lam_X, amp_X, Xr, lam_X, amp_X)
+    K[np.diag_indices(N)] += np.asarray(noise_X, np.float64) ** 2
+    try:
+        L = sla.cholesky(K, lower=True, check_finite=False)
+    except np.linalg.LinAlgError as e:
+        raise PosDefException(str(e))
+    delta = y - _mean_vec(mean, X)
+    z = sla.solve_triangular(L, delta, lower=True, check_finite=False)
+    a = sla.solve_triangular(L, z, lower=True, trans="T", check_finite=False)
+    logpdf = -0.5 * (N * _LOG2PI + 2.0 * float(np.sum(np.log(np.diag(L)))) + float(z @ z))
+    return NonstationaryPosterior(X, np.asarray(lam_X, np.float64), np.asarray(amp_X, np.float64),
+                                  None if discrete is None else np.asarray(discrete, bool), L, a, logpdf)
+
+
+def nonstationary_mean_and_var(post: NonstationaryPosterior, Xs, lam_Xs, amp_Xs, mean_s=None, clip: bool = True):
+    """mean_and_var of the GaussianProcessPosterior built over the NonstationaryKernel (gaussian_process.jl:174-178):
+    k(x*,x*) = α(x*)², + 1e-18, then _clip_var."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    Ks = gibbs_kernel_matrix(discrete_round(post.X, post.discrete), post.lam_X, post.amp_X,
+                             discrete_round(Xs, post.discrete), lam_Xs, amp_Xs)
+    mu = _mean_vec(mean_s, Xs) + Ks.T @ post.a
+    V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
+    var = np.asarray(amp_Xs, np.float64) ** 2 - np.sum(V * V, axis=0) + PREDICT_JITTER
+    return mu, (clip_var(var) if clip else var)

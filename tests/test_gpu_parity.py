@@ -1148,3 +1148,127 @@ def test_gradient_gp_full_size(api, O):
     mu_s, var_s = g.predict(Xs[:, 100:133])                                      # few-candidates path vs fused kernel
     assert np.allclose(mu_s, mu[100:133], rtol=0, atol=1e-9) and np.allclose(var_s, var[100:133], rtol=0, atol=1e-9)
     g.close()
+
+
+# ------------------------------------------------------------------------------------------
+# NonstationaryGP — the Gibbs kernel with input-dependent λ(x), α(x), σ(x)
+# ------------------------------------------------------------------------------------------
+def latent(d):
+    f_lam = lambda x: 0.25 + 0.5 * np.asarray(x) ** 2 + 0.1 * np.arange(1, d + 1)        # noqa: E731
+    f_amp = lambda x: 1.0 + 0.4 * np.sin(3 * x[0])                                        # noqa: E731
+    f_noise = lambda x: 0.03 + 0.05 * x[-1] ** 2                                           # noqa: E731
+    return f_lam, f_amp, f_noise
+
+
+@pytest.mark.parametrize("d,N,M", [(1, 1, 2), (2, 50, 33), (8, 300, 70), (3, 1100, 40), (20, 200, 65)])
+def test_nonstationary_gp_parity(api, O, d, N, M):
+    """Gibbs Gram + factor + logpdf + mean_and_var against the oracle (fused kernel below 1024 rows, the
+    few-candidates path above), with a prior mean."""
+    X, y, Xs = make(d, N, M, seed=4)
+    f_lam, f_amp, f_noise = latent(d)
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                   # noqa: E731
+    lamX, ampX, noiX = ev(f_lam, X).T, ev(f_amp, X), ev(f_noise, X)
+    lamS, ampS = ev(f_lam, Xs).T, ev(f_amp, Xs)
+    mX, mS = 0.3 * X[0], 0.3 * Xs[0]
+    post = O.nonstationary_fit(X, y, lamX, ampX, noiX, mean=mX)
+    mu_o, var_o = O.nonstationary_mean_and_var(post, Xs, lamS, ampS, mean_s=mS, clip=False)
+    K = post.L @ post.L.T
+    tol = max(1e-9, np.linalg.cond(K) * N * 2.0 ** -53 * 8)
+    g = api.GibbsGP(X, y)
+    lp = g.update(lamX, ampX, noiX, mX)
+    L, z = g.factor()
+    assert abs(lp - post.logpdf) <= tol * (1 + abs(post.logpdf))
+    assert np.abs(L - post.L).max() <= tol * np.abs(post.L).max()
+    mu, var = g.predict(Xs, lamS, ampS, mS)
+    assert np.abs(mu - mu_o).max() <= tol * (1 + np.abs(mu_o).max())
+    assert np.abs(var - np.where(var_o >= 0, var_o, 0.0)).max() <= tol * ampS.max() ** 2
+    mu1, var1 = g.predict(Xs[:, :1], lamS[:, :1], ampS[:1], mS[:1])
+    assert abs(mu1[0] - mu_o[0]) <= tol * (1 + abs(mu_o[0])) and abs(var1[0] - max(var_o[0], 0.0)) <= tol * ampS.max() ** 2
+    g.close()
+
+
+def test_nonstationary_gp_constant_parameters_equal_the_sqexp_model(api, O):
+    """With constant latent parameters the Gibbs kernel is the ARD squared-exponential kernel: the nonstationary
+    entry points must reproduce the plain ones on the device as well (the plain model adds 1e-8 to its parameters)."""
+    d, N, M = 4, 500, 16400                                  # M >= 16384: the 64-candidate tiles
+    X, y, Xs = make(d, N, M, seed=6)
+    lam, amp, sig = np.linspace(0.4, 0.9, d), 1.2, 0.05
+    gp = api.GP(X, y, "sqexp")
+    lp_p = gp.update(lam - 1e-8, amp - 1e-8, sig - 1e-8)
+    mu_p, var_p = gp.predict(Xs)
+    g = api.GibbsGP(X, y)
+    lp = g.update(np.tile(lam[:, None], (1, N)), np.full(N, amp), np.full(N, sig))
+    mu, var = g.predict(Xs, np.tile(lam[:, None], (1, M)), np.full(M, amp))
+    assert abs(lp - lp_p) <= 1e-9 * (1 + abs(lp_p))
+    assert np.allclose(mu, mu_p, rtol=0, atol=1e-9) and np.allclose(var, var_p, rtol=0, atol=1e-9)
+    gp.close()
+    g.close()
+
+
+def test_nonstationary_gp_discrete_errors_and_host_mirror(api, O):
+    import boss_jl_amd as B
+    rng = np.random.default_rng(12)
+    d, N, M = 2, 60, 45
+    X = rng.uniform(0, 5, (d, N))
+    Y = np.stack([np.sin(X[0]) + 0.1 * X[1], np.cos(X).sum(0)])
+    Xs = np.asfortranarray(rng.uniform(0, 5, (d, M)))
+    disc = np.array([False, True])
+    f_lam = lambda x: 0.8 + 0.1 * np.asarray(x)                                           # noqa: E731
+    f_amp = lambda x: 1.0 + 0.05 * x[1]                                                   # noqa: E731
+    f_noise = lambda x: 0.05 + 0.01 * x[0]                                                # noqa: E731
+    model = B.HipNonstationaryGP([f_lam, f_lam], [f_amp, f_amp], [f_noise, f_noise], mean=[lambda x: 0.1, None], discrete=disc)
+    data = B.ExperimentData(X, Y)
+    posts = model.model_posterior(data)
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                   # noqa: E731
+    Xr, Xsr = O.discrete_round(X, disc), O.discrete_round(Xs, disc)
+    tot = 0.0
+    for i in range(2):
+        mean = None if i else np.full(N, 0.1)
+        op = O.nonstationary_fit(X, Y[i], ev(f_lam, Xr).T, ev(f_amp, Xr), ev(f_noise, X), mean=mean, discrete=disc)
+        tot += op.logpdf
+        mu_o, var_o = O.nonstationary_mean_and_var(op, Xs, ev(f_lam, Xsr).T, ev(f_amp, Xsr), mean_s=None if i else np.full(M, 0.1))
+        mu, var = posts[i].mean_and_var(Xs)
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+        m1, v1 = posts[i].mean_and_var(Xs[:, 4])
+        assert abs(m1 - mu_o[4]) <= 1e-9 and abs(v1 - var_o[4]) <= 1e-9
+    assert abs(model.data_loglike(data) - tot) <= 1e-9 * (1 + abs(tot))
+    # EI on the predicted moments (the acquisition route for these posteriors)
+    mom = [p.mean_and_var(Xs) for p in posts]
+    mu, var = np.stack([m[0] for m in mom]), np.stack([m[1] for m in mom])
+    acq, am, mx = api.acq_ei_moments(mu[None], var[None], [1.0, 0.0], [np.inf, 1.0], 0.5, None)
+    want = O.expected_improvement_lin([1.0, 0.0], mu, var, 0.5) * O.feas_prob(mu, var, [np.inf, 1.0])
+    assert np.allclose(acq, want, rtol=0, atol=1e-12) and am == int(np.argmax(want))
+    g = posts[0].gp
+    for call in (lambda: api.GP.update(g, [1.0, 1.0], 1.0, 0.1), lambda: api.GP.predict(g, Xs), lambda: g.append(X[:, :1], [0.0]),
+                 lambda: g.predict_grad(Xs), lambda: g.predict_cov(Xs), lambda: g.loglike_grad(),
+                 lambda: api.acq_ei([[g]], api.Candidates(Xs), [1.0], None, 0.0, None),
+                 lambda: g.update(np.zeros((d, N)), np.ones(N), np.ones(N)),             # λ = 0
+                 lambda: g.update(np.ones((d, N)), -np.ones(N), np.ones(N))):
+        with pytest.raises(api.BossError):
+            call()
+    # identical points without noise -> PosDefException; data_loglike maps it to -Inf (safe_data_loglike)
+    Xd = np.tile(X[:, :1], (1, 4))
+    gd = api.GibbsGP(Xd, np.arange(4.0))
+    with pytest.raises(api.PosDefException):
+        gd.update(np.ones((d, 4)), np.ones(4), np.zeros(4))
+    gd.close()
+    for p in posts:
+        p.close()
+
+
+def test_nonstationary_gp_full_size(api, O):
+    """N = 4096, d = 8, 8192 candidates with input-dependent λ, α, σ: against the oracle's LAPACK fit."""
+    d, N, M = 8, 4096, 8192
+    X, y, Xs = make(d, N, M, seed=1)
+    f_lam, f_amp, f_noise = latent(d)
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                   # noqa: E731
+    lamX, ampX, noiX = ev(f_lam, X).T, ev(f_amp, X), ev(f_noise, X)
+    lamS, ampS = ev(f_lam, Xs).T, ev(f_amp, Xs)
+    post = O.nonstationary_fit(X, y, lamX, ampX, noiX)
+    g = api.GibbsGP(X, y)
+    lp = g.update(lamX, ampX, noiX)
+    assert abs(lp - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf))
+    mu, var = g.predict(Xs, lamS, ampS)
+    mu_o, var_o = O.nonstationary_mean_and_var(post, Xs[:, :512], lamS[:, :512], ampS[:512])
+    assert np.allclose(mu[:512], mu_o, rtol=0, atol=1e-9) and np.allclose(var[:512], var_o, rtol=0, atol=1e-9)
+    g.close()

@@ -261,3 +261,40 @@ def test_gradient_gp_with_uninformative_gradients_reduces_to_the_plain_gp():
     mu_g, var_g = O.gradient_gp_mean_and_var(post, Xt)
     mu_p, var_p = O.gp_mean_and_var(plain, Xt, clip=False)
     assert np.allclose(mu_g, mu_p, atol=1e-8) and np.allclose(var_g, var_p, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------
+# NonstationaryGP restatement: constant latent parameters reduce the Gibbs kernel to the ARD
+# squared-exponential one, i.e. to the pinned plain-GP oracle.
+# ------------------------------------------------------------------------------------------
+def test_gibbs_kernel_with_constant_parameters_is_the_sqexp_gp():
+    rng = np.random.default_rng(4)
+    d, N, M = 3, 40, 25
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0)
+    Xs = rng.uniform(0, 1, (d, M))
+    lam, amp, sig = np.array([0.4, 0.7, 1.1]), 1.3, 0.05
+    plain = O.gp_fit(X, y, O.SQEXP, lam - 1e-8, amp - 1e-8, sig - 1e-8)          # the plain model adds 1e-8, this one does not
+    ones = np.ones
+    post = O.nonstationary_fit(X, y, lam[:, None] * ones((d, N)), amp * ones(N), sig * ones(N))
+    assert abs(post.logpdf - plain.logpdf) <= 1e-9 * (1 + abs(plain.logpdf))
+    mu, var = O.nonstationary_mean_and_var(post, Xs, lam[:, None] * ones((d, M)), amp * ones(M))
+    mu_p, var_p = O.gp_mean_and_var(plain, Xs)
+    assert np.allclose(mu, mu_p, rtol=0, atol=1e-9) and np.allclose(var, var_p, rtol=0, atol=1e-9)
+
+
+def test_gibbs_kernel_is_positive_definite_and_symmetric_for_varying_lengthscales():
+    rng = np.random.default_rng(5)
+    d, N = 2, 60
+    X = rng.uniform(0, 1, (d, N))
+    lam = 0.1 + X ** 2                                  # λ_i(x) varies with the input
+    amp = 1.0 + 0.5 * X[0]
+    K = O.gibbs_kernel_matrix(X, lam, amp, X, lam, amp)
+    assert np.allclose(K, K.T, rtol=0, atol=1e-15) and np.allclose(np.diag(K), amp ** 2)
+    assert np.linalg.eigvalsh(K).min() > -1e-10
+    # the scalar definition (nonstationary_gp.jl:101-103) for one pair
+    k = ((amp[3] + amp[7]) / 2) ** 2
+    for i in range(d):
+        s = lam[i, 3] ** 2 + lam[i, 7] ** 2
+        k *= np.sqrt(2 * lam[i, 3] * lam[i, 7] / s) * np.exp(-(X[i, 3] - X[i, 7]) ** 2 / s)
+    assert abs(K[3, 7] - k) <= 1e-15
