@@ -217,4 +217,32 @@ function data_loglike(m::HipGradientGaussianProcess, data::BOSS.GradientData)
     h = ggp_create(m, data, 1)                    # per-output likelihood of the sliced model (gradient_gp.jl:367-397)
     return p -> try ggp_update(h, p, 1) catch e; e isa PosDefException ? -Inf : rethrow() end
 end
+# ---------------------------------------------------------------- NonstationaryGP (Gibbs kernel)
+# The latent models stay BOSS's own (ParametrizedGP posteriors or constants); only their values cross the ABI.
+struct HipNonstationaryPosterior <: BOSS.ModelPosteriorSlice{BOSS.NonstationaryGP}
+    post::HipPosteriorSlice; f_λ; f_α; discrete
+end
+rounded(X, ::Nothing) = X
+rounded(X, disc) = (Xr = copy(X); Xr[disc, :] .= round.(Xr[disc, :]); Xr)
+function hip_posterior_slice(model::BOSS.NonstationaryGP, params::BOSS.NonstationaryGPParams, data::BOSS.ExperimentData,
+                             i::Int; device = 0)
+    f_λ = BOSS._param_posterior_slice(model.lengthscale_model, params.λ, data, i)
+    f_α = BOSS._param_posterior_slice(model.amplitude_model, params.α, data, i)
+    f_σ = BOSS._param_posterior_slice(model.noise_std_model, params.σ, data, i)
+    X = Matrix{Float64}(data.X); Xr = rounded(X, model.discrete); mu = BOSS.mean_getindex(model.mean, i)
+    h = Ref{Ptr{Cvoid}}(); lp = Ref{Cdouble}()
+    check(ccall((:boss_ngp_create, lib), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+          device, size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]), isnothing(model.discrete) ? C_NULL : UInt8.(model.discrete), h))
+    check(ccall((:boss_ngp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{Cdouble}),
+          h[], reduce(hcat, f_λ.(eachcol(Xr))), Float64.(f_α.(eachcol(Xr))), Float64.(f_σ.(eachcol(X))), mean_vals(mu, X), 0, lp))
+    return HipNonstationaryPosterior(HipPosteriorSlice(h[], mu), f_λ, f_α, model.discrete), lp[]   # lp = data_loglike_slice
+end
+function mean_and_var(p::HipNonstationaryPosterior, X::AbstractMatrix{<:Real})
+    Xs = Matrix{Float64}(X); Xr = rounded(Xs, p.discrete); M = size(Xs, 2)
+    μ = Vector{Float64}(undef, M); σ2 = similar(μ); bad = Ref{Clong}(-1)
+    check(ccall((:boss_ngp_predict, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}),
+        p.post.h, M, Xs, reduce(hcat, p.f_λ.(eachcol(Xr))), Float64.(p.f_α.(eachcol(Xr))), mean_vals(p.post.mean, Xs), μ, σ2, bad))
+    return μ, σ2
+end
 end # module

@@ -330,6 +330,38 @@ def ggp_timing(d=8, n=4096, M=8192):
     g.close()
 
 
+def ngp_timing(d=8, N=4096, M=8192):
+    X, y, Xs = problem(d, N, M)
+    lamX = 0.25 + 0.5 * X ** 2
+    ampX = 1.0 + 0.4 * np.sin(3 * X[0])
+    noiX = 0.03 + 0.05 * X[-1] ** 2
+    lamS = 0.25 + 0.5 * Xs ** 2
+    ampS = 1.0 + 0.4 * np.sin(3 * Xs[0])
+    g = api.GibbsGP(X, y)
+    g.update(lamX, ampX, noiX)
+    g.predict(Xs, lamS, ampS)
+    t = time.time()
+    for _ in range(10):
+        g.update(lamX, ampX, noiX)
+    t_up = (time.time() - t) / 10
+    t = time.time()
+    for _ in range(10):
+        g.predict(Xs, lamS, ampS)
+    t_pr = (time.time() - t) / 10
+    t = time.time()
+    for i in range(20):
+        g.predict(Xs[:, i:i + 1], lamS[:, i:i + 1], ampS[i:i + 1])
+    t_one = (time.time() - t) / 20
+    api.prof_enable(0, True)
+    api.prof_reset(0)
+    g.update(lamX, ampX, noiX)
+    g.predict(Xs, lamS, ampS)
+    print(f"nonstationary N={N} d={d}: update {t_up*1e3:.2f} ms, predict({M}) {t_pr*1e3:.2f} ms, one candidate {t_one*1e3:.2f} ms; "
+          f"gram {api.prof_get(0, 'gram')[0]:.3f} ms, predict scope {api.prof_get(0, 'predict')[0]:.3f} ms", flush=True)
+    api.prof_enable(0, False)
+    g.close()
+
+
 if __name__ == "__main__":
     stages = sys.argv[1:] or ["mfma", "parity", "timing"]
     if "mfma" in stages:
@@ -348,6 +380,8 @@ if __name__ == "__main__":
         ggp_parity(8, 150, 40, "sqexp", dup=True)
     if "ggp_big" in stages:
         ggp_timing(n=int(os.environ.get("GGP_N", "1024")))
+    if "ngp" in stages:
+        ngp_timing()
     if "parity_big" in stages:
         parity(8, 4096, 512)
     if "timing" in stages:
