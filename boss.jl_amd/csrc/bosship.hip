@@ -205,6 +205,9 @@ struct boss_track {                            // resident predictive state of (
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// largest system the entry points accept: element offsets into the factor stay below 2^31 (exercised up to
+// 36 864 rows = 10.9 GB by the tests)
+constexpr int MAX_ROWS = 46080;
 
 // ------------------------------------------------------------------------------------------
 // library
@@ -438,6 +441,7 @@ static int gp_create_common(int device, int kernel, int d, int npts, int N, cons
     *out = nullptr;
     if (kernel < 0 || kernel > 2) return fail(BOSS_E_INVALID, "unknown kernel id");
     if (d < 1 || N < 1 || !X || !y) return fail(BOSS_E_INVALID, "need d >= 1, N >= 1 and non-NULL X, y");
+    if (N > MAX_ROWS) return fail(BOSS_E_INVALID, "more than 46080 rows (observations, or n (1 + d) with gradients) are not supported");
     Ctx* c;
     int rc = get_ctx(device, &c);
     if (rc) return rc;
@@ -517,7 +521,7 @@ extern "C" int boss_ggp_create(int device, int kernel, int d, int n, const doubl
     *out = nullptr;
     if (d < 1 || n < 1 || !X || !y || !dY) return fail(BOSS_E_INVALID, "need d >= 1, n >= 1 and non-NULL X, y, dY");
     if (d > AUG_MAX_D) return fail(BOSS_E_INVALID, "gradient observations: x_dim above 16 is not supported");
-    if ((long long)n * (1 + d) > 200000) return fail(BOSS_E_INVALID, "augmented system too large (n (1 + d) > 200000)");
+    if ((long long)n * (1 + d) > MAX_ROWS) return fail(BOSS_E_INVALID, "augmented system too large (n (1 + d) > 46080)");
     // `_build_obs_vector` (gradient_gp.jl:288-302): [y_1..n, ∂y/∂x_1 (1..n), …, ∂y/∂x_d (1..n)]
     std::vector<double> yt((size_t)n * (1 + d));
     for (int j = 0; j < n; ++j) {
@@ -810,6 +814,7 @@ extern "C" int boss_gp_sync(boss_gp_t* g, double* logpdf_out) {
 // any other — the right-looking factorisation restricted to one block row, O(N²) per 128 rows.
 // ------------------------------------------------------------------------------------------
 static int gp_grow(boss_gp* g, int Nnew) {
+    if (Nnew > MAX_ROWS) return fail(BOSS_E_INVALID, "more than 46080 observations are not supported");
     const int Np2 = round_up(Nnew, PRED_RB);
     if (Np2 <= g->Np) return BOSS_OK;
     Ctx* c = g->ctx;

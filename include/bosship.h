@@ -74,6 +74,7 @@ int boss_device_sync(int device);
  *            Semiparametric parametric mean (src/models/semiparametric.jl:79-84) are evaluated
  *            by the caller;
  *   logpdf_out  log marginal likelihood -(N log 2pi + logdet C + ||C.U'\(y-m)||^2)/2, may be NULL.
+ * N is limited to 46080 observations per handle (BOSS_E_INVALID beyond).
  * On a non-PD matrix returns BOSS_E_NOT_PD, *logpdf_out = -Inf (what safe_data_loglike yields,
  * src/surrogate_model.jl:2-12) and the handle is left unfitted. */
 int boss_gp_create(int device, int kernel, int d, int N, const double* X, const double* y,
@@ -138,7 +139,7 @@ int boss_gp_get_factor(const boss_gp_t* gp, double* L_out, double* z_out);
  * and boss_gp_free work on it; the entry points that assume value-only observations (boss_gp_update,
  * boss_gp_set_y, boss_gp_append, boss_gp_reserve, boss_gp_predict_grad, boss_gp_predict_cov,
  * boss_gp_loglike_grad, boss_acq_ei_grad, boss_track_create) return BOSS_E_INVALID.
- * Limits: d <= 16, n(1+d) <= 200000. */
+ * Limits: d <= 16, n(1+d) <= 46080. */
 int boss_ggp_create(int device, int kernel, int d, int n, const double* X, const double* y, const double* dY,
                     boss_gp_t** out);
 int boss_ggp_update(boss_gp_t* gp, const double* lengthscale, double amplitude, double noise_std,

@@ -52,6 +52,19 @@ def test_no_gpu_fails_loudly_and_validates_arguments():
     with pytest.raises(api.BossError) as e:
         api.fit(np.zeros((2, 3)), np.zeros(3), "matern52", [1.0], 1.0, 1.0)
     assert e.value.code == api.BOSS_E_INVALID
+    # the size limit, the gradient model's x_dim limit and the new models' entry points without a device
+    with pytest.raises(api.BossError) as e:
+        api.GP(np.zeros((1, 46081)), np.zeros(46081))
+    assert e.value.code == api.BOSS_E_INVALID and "46080" in str(e.value)
+    with pytest.raises(api.BossError) as e:
+        api.GradGP(np.zeros((17, 2)), np.zeros(2), np.zeros((17, 2)))
+    assert e.value.code == api.BOSS_E_INVALID
+    with pytest.raises(api.BossError) as e:
+        api.GradGP(np.zeros((2, 3)), np.zeros(3), np.zeros((2, 3)))
+    assert e.value.code == api.BOSS_E_NO_DEVICE
+    with pytest.raises(api.BossError) as e:
+        api.GibbsGP(np.zeros((2, 3)), np.zeros(3))
+    assert e.value.code == api.BOSS_E_NO_DEVICE
 
 
 def test_product_path_never_imports_oracle():
