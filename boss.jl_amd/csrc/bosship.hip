@@ -301,7 +301,7 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
     }
     static const int small_m = getenv("BOSS_SMALL_M") ? atoi(getenv("BOSS_SMALL_M")) : 12;
     static const bool no_pairs = getenv("BOSS_NO_PAIRS") && atoi(getenv("BOSS_NO_PAIRS"));
-    int kstart = 0;
+    int kstart = 0, tail_join = -1;
     if (la && !no_pairs && batch == 1 && nblk - 1 > small_m + 2) {
         // ---- paired look-ahead: the bulk update applies TWO panels at a time (K = 256: half the trailing-matrix
         // traffic, better tile efficiency, half the events) and has TWO steps of slack:
@@ -340,10 +340,13 @@ static void potrf_enqueue(Ctx* c, double* A, int ld, int Np, int batch, size_t b
                 }
             }
         }
-        if (last >= 0) (void)hipStreamWaitEvent(s, c->ev_rest[last], 0);
+        // the last bulk update still runs on the side stream; the tail's first diagonal block and panel solve touch
+        // only block column k (brought up to date by the column updates above), so the join waits until the tail's
+        // first trailing update
+        tail_join = last;
         kstart = k;
     }
-    int last_rest = -1;
+    int last_rest = tail_join;
     for (int k = kstart; k < nblk; ++k) {
         {
             ProfScope ps(c, "potrf_diag");
