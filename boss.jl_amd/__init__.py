@@ -14,5 +14,5 @@ from .model import HipGaussianProcess, HipGPParams, average_mean  # noqa: F401,E
 from .gradient_gp import (GradientData, HipGradientGaussianProcess, HipGradientGPParams,  # noqa: F401,E402
                           join_gradient_slices)
 from .nonstationary import HipNonstationaryGP  # noqa: F401,E402
-from .fitter import HipBatchedMAP, HipGradientMAP, MAPParams  # noqa: F401,E402
+from .fitter import HipBatchedMAP, HipGradientMAP, HipSampleOptMAP, MAPParams  # noqa: F401,E402
 from .maximizer import HipBatchAM, HipGradientAM, HipSequentialBatchAM  # noqa: F401,E402

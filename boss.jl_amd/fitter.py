@@ -75,6 +75,7 @@ class HipGradientMAP:
     seed: Optional[int] = None
     group: object = None
     step0: float = 0.3
+    starts: Optional[List[HipGPParams]] = None       # set_starts (optimization.jl): given starts replace the prior draws
 
     def _objective(self, model, prior_ll, gps, data, p: HipGPParams):
         """(log-posterior, gradient w.r.t. (λ[d,P], α[P], σ[P])) — gradient of the data term from the device."""
@@ -102,9 +103,13 @@ class HipGradientMAP:
         data = problem.data
         rng = np.random.default_rng(self.seed)
         sampler, prior_ll = model.params_sampler(), model.params_loglike()
-        starts: List[HipGPParams] = [sampler(rng) for _ in range(self.multistart)]       # same stream on every rank
+        if self.starts is not None:
+            starts: List[HipGPParams] = list(self.starts)
+        else:
+            starts = [sampler(rng) for _ in range(self.multistart)]                      # same stream on every rank
+        nstart = len(starts)
         rank, world = dist_util.rank_world(self.group)
-        lo, hi = dist_util.shard_range(self.multistart, rank, world)
+        lo, hi = dist_util.shard_range(nstart, rank, world)
         P = data.Y.shape[0]
         free_l = np.array([not isinstance(pr, (Dirac, MvDirac)) for pr in model.lengthscale_priors])
         free_a = np.array([not isinstance(pr, Dirac) for pr in model.amplitude_priors])
@@ -146,7 +151,7 @@ class HipGradientMAP:
         if return_all:
             return [MAPParams(p, f) for _, p, f in results]
         best = max(results, key=lambda r: (r[2], -r[0])) if results else None
-        best_v, best_i = (best[2], best[0]) if best else (-np.inf, self.multistart)
+        best_v, best_i = (best[2], best[0]) if best else (-np.inf, nstart)
         best_v, gi = dist_util.argmax_exchange(best_v, best_i, self.group)
         if world == 1:
             return MAPParams(best[1], best_v)
@@ -156,3 +161,25 @@ class HipGradientMAP:
         flat = dist_util.allgather_concat(flat, self.group)
         d = data.X.shape[0]
         return MAPParams(HipGPParams(flat[:d * P].reshape(d, P, order="F"), flat[d * P:d * P + P], flat[d * P + P:]), best_v)
+
+
+@dataclass
+class HipSampleOptMAP:
+    """SampleOptMAP (src/model_fitters/sample_opt.jl:14-49): draw `samples` prior samples, score them with the
+    batched likelihood (HipBatchedMAP, return_all), start `multistart` gradient ascents (HipGradientMAP) from the
+    best ones."""
+    samples: int = 2000
+    multistart: int = 20
+    iters: int = 40
+    seed: Optional[int] = None
+    group: object = None
+
+    def __post_init__(self):
+        assert self.samples >= self.multistart                       # sample_opt.jl:30
+
+    def estimate_parameters(self, problem: BossProblem, options: BossOptions = BossOptions(), return_all: bool = False):
+        scored = HipBatchedMAP(self.samples, self.seed, self.group).estimate_parameters(problem, options, return_all=True)
+        order = sorted(range(len(scored)), key=lambda i: -scored[i].loglike)             # sortperm(...; rev=true), stable
+        starts = [scored[i].params for i in order[:self.multistart]]
+        opt = HipGradientMAP(self.multistart, self.iters, self.seed, self.group, starts=starts)
+        return opt.estimate_parameters(problem, options, return_all)

@@ -898,6 +898,16 @@ def test_gradient_map_fitter_improves_on_its_starts(api, O):
     assert best.loglike == max(r.loglike for r in allr)
     sampled = B.HipBatchedMAP(samples=200, seed=3).estimate_parameters(prob)
     assert best.loglike >= sampled.loglike - 1e-6
+    # SampleOptMAP (sample_opt.jl:38-49): the ascents start from the best prior samples, so each result is at least as
+    # good as the sample it started from and the winner at least as good as plain sampling
+    so = B.HipSampleOptMAP(samples=200, multistart=3, iters=10, seed=3)
+    scored = B.HipBatchedMAP(samples=200, seed=3).estimate_parameters(prob, return_all=True)
+    top = sorted(scored, key=lambda r: -r.loglike)[:3]
+    res = so.estimate_parameters(prob, return_all=True)
+    assert len(res) == 3 and all(r.loglike >= t.loglike - 1e-9 for r, t in zip(res, top))
+    assert so.estimate_parameters(prob).loglike >= sampled.loglike - 1e-9
+    with pytest.raises(AssertionError):
+        B.HipSampleOptMAP(samples=2, multistart=3)
 
 
 @pytest.mark.parametrize("N,M", [(1024, 1), (1100, 5), (2048, 32), (4096, 1)])
