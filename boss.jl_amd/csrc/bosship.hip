@@ -1863,8 +1863,22 @@ extern "C" int boss_gp_loglike_grad(boss_gp_t* g, double* logpdf_out, double* gr
         g->have_dinv = true;
     }
     typedef PredG32 G;
-    hipLaunchKernelGGL(linvt_kernel<G>, dim3(Np / 32), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->A, ld, Np,
-                       (const double*)g->Dinv2, LinvT, ld);
+    static const bool linvt_solve = getenv("BOSS_LINVT_SOLVE") && atoi(getenv("BOSS_LINVT_SOLVE"));   // A/B: the substitution
+    if (linvt_solve) {
+        hipLaunchKernelGGL(linvt_kernel<G>, dim3(Np / 32), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->A, ld, Np,
+                           (const double*)g->Dinv2, LinvT, ld);
+    } else {
+        // L⁻ᵀ by recursive doubling (see linv_level_kernel); the lower work matrix lives in the buffer K⁻¹ overwrites afterwards
+        double* Lw = Kinv;
+        hipLaunchKernelGGL(linv_seed_kernel, dim3(PRED_RB, Np / PRED_RB), dim3(PRED_RB), 0, s, (const double*)g->Dinv2, Lw, ld, LinvT, ld);
+        for (int sz = PRED_RB; sz < Np; sz *= 2) {
+            const int pairs = (Np + 2 * sz - 1) / (2 * sz), tiles = (sz / BLK) * (sz / BLK);
+            hipLaunchKernelGGL((linv_level_kernel<SyrkG, 1>), dim3(tiles, pairs), dim3(256), 0, s, (const double*)g->A, ld, Lw, ld,
+                               LinvT, ld, Np, sz);
+            hipLaunchKernelGGL((linv_level_kernel<SyrkG, 2>), dim3(tiles, pairs), dim3(256), 0, s, (const double*)g->A, ld, Lw, ld,
+                               LinvT, ld, Np, sz);
+        }
+    }
     hipLaunchKernelGGL(kinv_syrk_kernel<SyrkG>, dim3(g->nblk * (g->nblk + 1) / 2), dim3(256), 0, s, (const double*)LinvT, ld, Np, Kinv,
                        ld);
     hipLaunchKernelGGL(avec_partial_kernel, dim3(Np / 256, nch), dim3(256), 0, s, (const double*)LinvT, ld, Np, N,

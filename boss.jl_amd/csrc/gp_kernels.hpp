@@ -1088,6 +1088,73 @@ __global__ __launch_bounds__(G::NTHREADS) void linvt_kernel(const double* __rest
 }
 
 // needs SyrkG (potrf.hpp is included after this header by bosship.hip, so the kernel is templated on it)
+// L⁻¹ by recursive doubling instead of a substitution (the substitution's 32-column workgroups are
+// latency-bound and fill half the chip).  With L = [A 0; B C]:  L⁻ᵀ = [A⁻ᵀ  X; 0  C⁻ᵀ],  X = −(A⁻ᵀ Bᵀ) C⁻ᵀ.
+// Two work matrices: U = L⁻ᵀ (upper, what the consumers below read as LinvT) and Lw = L⁻¹ (lower); both GEMMs
+// are of the C += A·Bᵀ form of GemmDirect when the second factor is taken from the other matrix:
+//   phase 1   T1 = U_A · Bᵀ            (T1 parked in Lw's structurally-zero upper-right block; k ≥ row block: U_A is upper)
+//   phase 2   X  = −T1 · (Lw_C)ᵀ       (k ≤ column block: Lw_C is lower)   → U[A-range, C-range] = X,  Lw[C-range, A-range] = Xᵀ
+// Seeded with the 256×256 diagonal inverses (Dinv2), then chunk sizes s = 256, 512, … ; one launch per phase and level,
+// grid.y = pair of chunks (the last pair may be ragged or absent: Np/256 need not be a power of two).
+__global__ __launch_bounds__(256) void linv_seed_kernel(const double* __restrict__ Dinv2, double* __restrict__ Lw, int ldw,
+                                                        double* __restrict__ U, int ldu) {
+    const int b = blockIdx.y, c = blockIdx.x, r = threadIdx.x;
+    const double v = (r >= c) ? Dinv2[(size_t)b * PRED_RB * PRED_RB + r + (size_t)c * PRED_RB] : 0.0;   // upper half holds scratch
+    const size_t o = (size_t)b * PRED_RB;
+    Lw[(o + r) + (o + c) * ldw] = v;
+    U[(o + c) + (o + r) * ldu] = v;
+}
+
+template <class SG, int PHASE>
+__global__ __launch_bounds__(256, 2) void linv_level_kernel(const double* __restrict__ Afac, int ld, double* __restrict__ Lw,
+                                                            int ldw, double* __restrict__ U, int ldu, int Np, int s) {
+    const int a0 = 2 * blockIdx.y * s, c0 = a0 + s;
+    if (c0 >= Np) return;                                    // unpaired last chunk
+    const int sC = (Np - c0 < s) ? Np - c0 : s;
+    const int tm = s / BLK, tn = sC / BLK;
+    const int t = blockIdx.x;
+    if (t >= tm * tn) return;
+    const int mi = t % tm, ni = t / tm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / SG::WC, wc = wave % SG::WC;
+    v4d acc[SG::TM][SG::TN];
+#pragma unroll
+    for (int m = 0; m < SG::TM; ++m)
+#pragma unroll
+        for (int n = 0; n < SG::TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    const size_t r0 = (size_t)a0 + mi * BLK, q0 = (size_t)c0 + ni * BLK;
+    if (PHASE == 1) {
+        const int k0 = mi * BLK;
+        SG::template run<1>(U + r0 + ((size_t)a0 + k0) * ldu, ldu, Afac + q0 + ((size_t)a0 + k0) * ld, ld, s - k0, acc);
+        double* T1 = Lw + r0 + q0 * ldw;
+#pragma unroll
+        for (int m = 0; m < SG::TM; m += 2)
+#pragma unroll
+            for (int n = 0; n < SG::TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v2d c2 = {acc[m][n][i], acc[m + 1][n][i]};
+                    *reinterpret_cast<v2d*>(T1 + SG::row_of(wr, m, lane) + (size_t)SG::col_of(wc, n, i, lane) * ldw) = c2;
+                }
+    } else {
+        SG::template run<1>(Lw + r0 + (size_t)c0 * ldw, ldw, Lw + q0 + (size_t)c0 * ldw, ldw, (ni + 1) * BLK, acc);
+        double* X = U + r0 + q0 * ldu;
+        double* Xt = Lw + q0 + r0 * ldw;
+#pragma unroll
+        for (int m = 0; m < SG::TM; m += 2)
+#pragma unroll
+            for (int n = 0; n < SG::TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = SG::row_of(wr, m, lane), col = SG::col_of(wc, n, i, lane);
+                    v2d c2 = {-acc[m][n][i], -acc[m + 1][n][i]};
+                    *reinterpret_cast<v2d*>(X + row + (size_t)col * ldu) = c2;
+                    Xt[col + (size_t)row * ldw] = c2[0];
+                    Xt[col + (size_t)(row + 1) * ldw] = c2[1];
+                }
+    }
+}
+
 template <class SG>
 __global__ __launch_bounds__(256, 2) void kinv_syrk_kernel(const double* __restrict__ LinvT, int ldt, int Np,
                                                            double* __restrict__ Kinv, int ldk) {
