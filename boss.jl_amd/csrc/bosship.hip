@@ -45,6 +45,11 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------
 // per-device context: stream, grow-only workspaces, per-kernel-class event profiling
 // ------------------------------------------------------------------------------------------
+// pinned host block per device: results of the acquisition epilogue, then two staging areas that let calls with a
+// handful of candidates skip a stream synchronisation (upload) and two of three download copies
+constexpr size_t PINNED_BYTES = 64 * 1024, PINNED_UP_OFF = 4096, PINNED_UP_BYTES = 32 * 1024, PINNED_DOWN_OFF = 36 * 1024,
+                 PINNED_DOWN_BYTES = 28 * 1024;
+
 struct Workspace {
     void* p = nullptr;
     size_t bytes = 0;
@@ -56,7 +61,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // trailing updates of the look-ahead Cholesky
     std::vector<hipEvent_t> ev_panel, ev_rest;  // per-step dependency events (no timing)
-    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_up = nullptr;            // ev_up: last upload out of the pinned staging area
     bool lookahead = true;
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
@@ -95,13 +100,17 @@ static int get_ctx(int device, Ctx** out) {
         HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
     c->lookahead = !(getenv("BOSS_NO_LOOKAHEAD") && atoi(getenv("BOSS_NO_LOOKAHEAD")));
-    HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)few_back_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)few_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -187,6 +196,10 @@ struct boss_gp {
     // (rounded where discrete) training points
     bool gibbs = false;
     double *lamX = nullptr, *ampX = nullptr, *noiseX = nullptr;
+    // explicit L⁻ᵀ for calls with one to four candidates (built on the second such call on a factorisation)
+    double* Winv = nullptr;
+    bool have_winv = false;
+    int few_calls = 0;
 };
 
 struct boss_cand {
@@ -415,6 +428,7 @@ static void gp_release(boss_gp* g) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->host_res) (void)hipHostFree(g->host_res);
+    if (g->Winv) (void)hipFree(g->Winv);
     if (g->lamX) (void)hipFree(g->lamX);
     if (g->ampX) (void)hipFree(g->ampX);
     if (g->noiseX) (void)hipFree(g->noiseX);
@@ -687,6 +701,8 @@ extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double am
     hipStream_t s = c->stream;
     g->fitted = false;
     g->have_dinv = false;
+    g->have_winv = false;
+    g->few_calls = 0;
     g->have_lt = false;
     ++g->epoch;
     // +1e-8 on every parameter (gaussian_process.jl:239-241)
@@ -732,6 +748,8 @@ extern "C" int boss_ggp_update(boss_gp_t* g, const double* lengthscale, double a
     hipStream_t s = c->stream;
     g->fitted = false;
     g->have_dinv = false;
+    g->have_winv = false;
+    g->few_calls = 0;
     ++g->epoch;
     HIPCHK(hipEventSynchronize(g->par_ev));
     double* invlam = g->host_par;
@@ -778,6 +796,8 @@ extern "C" int boss_ngp_update(boss_gp_t* g, const double* lam_X, const double* 
     hipStream_t s = c->stream;
     g->fitted = false;
     g->have_dinv = false;
+    g->have_winv = false;
+    g->few_calls = 0;
     ++g->epoch;
     HIPCHK(hipMemcpyAsync(g->lamX, lam.data(), sizeof(double) * d * Np, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->ampX, amp.data(), sizeof(double) * Np, hipMemcpyHostToDevice, s));
@@ -854,11 +874,15 @@ static int gp_grow(boss_gp* g, int Nnew) {
     if (g->DT2) (void)hipFree(g->DT2);
     if (g->avec) (void)hipFree(g->avec);
     g->LT = g->DT2 = g->avec = nullptr;
+    if (g->Winv) (void)hipFree(g->Winv);
+    g->Winv = nullptr;
     g->Xraw = nw[0]; g->Xsc = nw[1]; g->y = nw[2]; g->mean = nw[3]; g->A = nw[4]; g->inv16 = nw[5]; g->Dinv = nw[6]; g->Dinv2 = nw[7];
     g->Np = Np2;
     g->nblk = nblk2;
     g->ld = ld2;
     g->have_dinv = false;
+    g->have_winv = false;
+    g->few_calls = 0;
     g->have_lt = false;
     return BOSS_OK;
 }
@@ -898,6 +922,8 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
     if (rc) return rc;
     g->fitted = false;
     g->have_dinv = false;
+    g->have_winv = false;
+    g->few_calls = 0;
     g->have_lt = false;
     {
         std::vector<double> xb;
@@ -1156,7 +1182,18 @@ static int temp_cand(Ctx* c, int d, int M, const double* Xs, boss_cand* cd) {
     cd->Craw = (double*)c->craw.p;
     std::vector<double> buf;
     pack_points(buf, Xs, d, M, cd->Mp, nullptr);
-    HIPCHK(hipMemcpyAsync(cd->Craw, buf.data(), sizeof(double) * d * cd->Mp, hipMemcpyHostToDevice, c->stream));
+    const size_t bytes = sizeof(double) * d * cd->Mp;
+    if (bytes <= PINNED_UP_BYTES) {
+        // few candidates: stage through pinned memory, no synchronisation (every entry point that calls this ends with
+        // a stream synchronisation before it returns, so the area is free again at the next call)
+        void* stage = (char*)c->pinned + PINNED_UP_OFF;
+        HIPCHK(hipEventSynchronize(c->ev_up));             // the previous upload from this area (normally long complete)
+        std::memcpy(stage, buf.data(), bytes);
+        HIPCHK(hipMemcpyAsync(cd->Craw, stage, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(c->ev_up, c->stream));
+        return BOSS_OK;
+    }
+    HIPCHK(hipMemcpyAsync(cd->Craw, buf.data(), bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));               // staging buffer goes out of scope
     return BOSS_OK;
 }
@@ -1180,6 +1217,18 @@ __global__ void scale_cand_kernel(const double* __restrict__ Craw, double* __res
         double v = Craw[(size_t)k * Mp + j];
         if (discrete && discrete[k]) v = rint(v);
         Csc[(size_t)k * Mp + j] = v * invlam[k];
+    }
+}
+
+// U = L⁻ᵀ (upper, leading dimension g->ld) by recursive doubling from the 256×256 diagonal inverses; Lw (same shape)
+// is the lower work matrix.  Dinv2 must be current on stream s.
+static void linv_enqueue(boss_gp* g, hipStream_t s, double* U, double* Lw) {
+    const int Np = g->Np, ld = g->ld;
+    hipLaunchKernelGGL(linv_seed_kernel, dim3(PRED_RB, Np / PRED_RB), dim3(PRED_RB), 0, s, (const double*)g->Dinv2, Lw, ld, U, ld);
+    for (int sz = PRED_RB; sz < Np; sz *= 2) {
+        const int pairs = (Np + 2 * sz - 1) / (2 * sz), tiles = (sz / BLK) * (sz / BLK);
+        hipLaunchKernelGGL((linv_level_kernel<SyrkG, 1>), dim3(tiles, pairs), dim3(256), 0, s, (const double*)g->A, ld, Lw, ld, U, ld, Np, sz);
+        hipLaunchKernelGGL((linv_level_kernel<SyrkG, 2>), dim3(tiles, pairs), dim3(256), 0, s, (const double*)g->A, ld, Lw, ld, U, ld, Np, sz);
     }
 }
 
@@ -1225,12 +1274,29 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         typedef GemmDirect<4, 1, 2, 2, 8> GU;                // 128×32 update tiles
         ProfScope ps(c, "predict");
         const int nb = g->Np / PRED_RB;
-        rc = ws_reserve(c->few, sizeof(double) * (size_t)ftiles * ((size_t)g->Np * 32 + 64));
+        const int nwg = g->Np / WINV_ROWS;
+        rc = ws_reserve(c->few, sizeof(double) * ((size_t)ftiles * ((size_t)g->Np * 32 + 64) + (size_t)nwg * 8));
         if (rc) return rc;
         double* R = (double*)c->few.p;                       // residuals [tile][Np][32], start as K*
         double* ssmz = R + (size_t)ftiles * g->Np * 32;
         double* V = (double*)c->vscratch.p;
-        (void)hipMemsetAsync(ssmz, 0, sizeof(double) * 64 * ftiles, s);
+        // one to four candidates, repeatedly on the same factorisation: a pass over the explicit L⁻ᵀ (winv_gemv_kernel)
+        static const int winv_after = getenv("BOSS_WINV_AFTER") ? atoi(getenv("BOSS_WINV_AFTER")) : 2;
+        const size_t winv_lds = sizeof(double) * (size_t)g->Np * WINV_MAX_M;
+        bool use_winv = false;
+        if (!for_grad && cd->M <= WINV_MAX_M && winv_lds <= 144 * 1024 && winv_after > 0) {
+            if (!g->have_winv && ++g->few_calls >= winv_after) {
+                bool ok = g->Winv != nullptr || hipMalloc((void**)&g->Winv, sizeof(double) * (size_t)g->ld * g->Np) == hipSuccess;
+                if (ok && ws_reserve(c->lgB, sizeof(double) * (size_t)g->ld * g->Np) == BOSS_OK) {
+                    linv_enqueue(g, s, g->Winv, (double*)c->lgB.p);
+                    g->have_winv = true;
+                } else {
+                    (void)hipGetLastError();             // no memory for the inverse: stay on the substitution path
+                }
+            }
+            use_winv = g->have_winv;
+        }
+        if (!use_winv) (void)hipMemsetAsync(ssmz, 0, sizeof(double) * 64 * ftiles, s);
         if (g->aug)
             hipLaunchKernelGGL(aug_kstar_kernel, dim3(g->Np / 256, ftiles), dim3(256), aug_lds, s, (const double*)g->Xraw, g->ldx,
                                g->d, g->npts, g->N, g->Np, (const double*)cd->Craw, Mp, g->kernel, g->amp2,
@@ -1241,7 +1307,21 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
                                (const double*)cd->Craw, clam_dev, camp_dev, Mp, R);
         else
             hipLaunchKernelGGL(kstar_rows_kernel, dim3(g->Np / 256, ftiles), dim3(256), sizeof(double) * g->d * 32, s,
-                               (const double*)g->Xsc, g->Np, g->N, (const double*)Csc, g->d, Mp, g->kernel, g->amp2, R);
+                               (const double*)g->Xsc, g->Np, g->N, (const double*)Csc, g->d, Mp, g->kernel, g->amp2, R,
+                               use_winv ? cd->M : 32);
+        if (use_winv) {
+            double* part = ssmz + 64 * (size_t)ftiles;
+            const int mc = cd->M == 1 ? 1 : cd->M == 2 ? 2 : 4;
+            const size_t lds = sizeof(double) * (size_t)g->Np * mc;
+            auto kfn = mc == 1 ? winv_gemv_kernel<1> : mc == 2 ? winv_gemv_kernel<2> : winv_gemv_kernel<4>;
+            hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), lds, s, (const double*)g->Winv, g->ld, g->Np,
+                               (const double*)g->A, g->ld, (const double*)R, cd->M, part);
+            hipLaunchKernelGGL(winv_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nwg, cd->M, mean_s_dev, g->amp2,
+                               g->aug ? 1 : g->gibbs ? 2 : 0, mu, var);
+            if (g->gibbs) hipLaunchKernelGGL(gibbs_var_kernel, dim3(1), dim3(256), 0, s, var, camp_dev, cd->M);
+            HIPCHK(hipGetLastError());
+            return BOSS_OK;
+        }
         for (int ib = 0; ib < nb; ++ib) {
             hipLaunchKernelGGL(few_finish_kernel<G>, dim3(ftiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s, (const double*)g->A,
                                g->ld, g->Np, ib, (const double*)R, (const double*)g->Dinv2, V, ssmz, ib == nb - 1 ? 1 : 0,
@@ -1312,11 +1392,11 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
     boss_cand* cd = &cand_tmp;
     int rc = temp_cand(c, g->d, M, Xs, cd);
     if (rc) return rc;
-    rc = ws_reserve(c->pred, sizeof(double) * (3 * (size_t)M + 2));   // mu | var | mean | bad
+    rc = ws_reserve(c->pred, sizeof(double) * (3 * (size_t)M + 2));   // mu | var | bad | mean
     if (rc) return rc;
     double* dev = (double*)c->pred.p;
-    double *dmu = dev, *dvar = dev + M, *dmean = dev + 2 * (size_t)M;
-    unsigned long long* dbad = (unsigned long long*)(dev + 3 * (size_t)M);
+    double *dmu = dev, *dvar = dev + M, *dmean = dev + 2 * (size_t)M + 1;
+    unsigned long long* dbad = (unsigned long long*)(dev + 2 * (size_t)M);
     hipStream_t s = c->stream;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(s);
@@ -1330,11 +1410,21 @@ extern "C" int boss_gp_predict(boss_gp_t* g, int M, const double* Xs, const doub
     }
     hipLaunchKernelGGL(clip_var_kernel, dim3((M + 255) / 256), dim3(256), 0, s, dvar, M, dbad);
     unsigned long long bad = 0;
-    (void)hipMemcpyAsync(mu, dmu, sizeof(double) * M, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(var, dvar, sizeof(double) * M, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost, s);
-    hipError_t e = hipStreamSynchronize(s);
-    cleanup();
+    const size_t down = sizeof(double) * (2 * (size_t)M + 1);
+    hipError_t e;
+    if (down <= PINNED_DOWN_BYTES) {                         // few candidates: one copy into pinned memory
+        double* stage = (double*)((char*)c->pinned + PINNED_DOWN_OFF);
+        (void)hipMemcpyAsync(stage, dev, down, hipMemcpyDeviceToHost, s);
+        e = hipStreamSynchronize(s);
+        std::memcpy(mu, stage, sizeof(double) * M);
+        std::memcpy(var, stage + M, sizeof(double) * M);
+        std::memcpy(&bad, stage + 2 * (size_t)M, sizeof bad);
+    } else {
+        (void)hipMemcpyAsync(mu, dmu, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(var, dvar, sizeof(double) * M, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost, s);
+        e = hipStreamSynchronize(s);
+    }
     if (e != hipSuccess) return fail(BOSS_E_NO_DEVICE, hipGetErrorString(e));
     if (bad != ~0ULL) {
         if (bad_index) *bad_index = (long)bad;
@@ -1869,15 +1959,7 @@ extern "C" int boss_gp_loglike_grad(boss_gp_t* g, double* logpdf_out, double* gr
                            (const double*)g->Dinv2, LinvT, ld);
     } else {
         // L⁻ᵀ by recursive doubling (see linv_level_kernel); the lower work matrix lives in the buffer K⁻¹ overwrites afterwards
-        double* Lw = Kinv;
-        hipLaunchKernelGGL(linv_seed_kernel, dim3(PRED_RB, Np / PRED_RB), dim3(PRED_RB), 0, s, (const double*)g->Dinv2, Lw, ld, LinvT, ld);
-        for (int sz = PRED_RB; sz < Np; sz *= 2) {
-            const int pairs = (Np + 2 * sz - 1) / (2 * sz), tiles = (sz / BLK) * (sz / BLK);
-            hipLaunchKernelGGL((linv_level_kernel<SyrkG, 1>), dim3(tiles, pairs), dim3(256), 0, s, (const double*)g->A, ld, Lw, ld,
-                               LinvT, ld, Np, sz);
-            hipLaunchKernelGGL((linv_level_kernel<SyrkG, 2>), dim3(tiles, pairs), dim3(256), 0, s, (const double*)g->A, ld, Lw, ld,
-                               LinvT, ld, Np, sz);
-        }
+        linv_enqueue(g, s, LinvT, Kinv);
     }
     hipLaunchKernelGGL(kinv_syrk_kernel<SyrkG>, dim3(g->nblk * (g->nblk + 1) / 2), dim3(256), 0, s, (const double*)LinvT, ld, Np, Kinv,
                        ld);

@@ -211,6 +211,20 @@ def few_timing(d=8, N=4096):
     g = api.GP(X, y, "matern52")
     g.update(np.full(d, 0.5), 1.0, 0.05)
     X, y, Xs = problem(d, N, 8300)
+    for M in (1, 4):                                         # steady state of the explicit-inverse path
+        for i in range(3):
+            g.predict(Xs[:, i:i + M])
+        t = time.time()
+        for i in range(300):
+            g.predict(Xs[:, i:i + M])
+        dt = (time.time() - t) / 300
+        api.prof_enable(0, True)
+        api.prof_reset(0)
+        g.predict(Xs[:, :M])
+        print(f"steady-state predict M={M}: {dt*1e3:.3f} ms per call ({M/dt:.0f} evals/s); device 'predict' scope "
+              f"{api.prof_get(0, 'predict')[0]*1e3:.1f} us", flush=True)
+        api.prof_enable(0, False)
+    g.update(np.full(d, 0.5), 1.0, 0.05)
     for M in (1, 32, 224, 1024, 2048, 4096, 8192):
         g.predict(Xs[:, :M])
         t = time.time()

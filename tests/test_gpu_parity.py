@@ -942,6 +942,79 @@ def test_few_candidates_path(api, O, N, M):
     g.close()
 
 
+@pytest.mark.parametrize("N,M", [(1024, 1), (1300, 3), (2048, 4), (4096, 1)])
+def test_repeated_few_candidate_calls_use_the_explicit_inverse(api, O, N, M):
+    """One to four candidates per call, many calls per posterior (the reference's `acq.(eachcol(xs))` pattern): from
+    the second call on a factorisation the handle predicts through the explicit L⁻ᵀ.  Every call agrees with the
+    oracle, and an update / append in between switches back to the new factor."""
+    rng = np.random.default_rng(N + 7 * M)
+    d = 3
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0) / 2 + 0.05 * rng.standard_normal(N)
+    mean = 0.1 * X[0]
+    lam = np.array([0.4, 0.5, 0.6])
+    g = api.GP(X, y, "matern52")
+    g.update(lam, 1.1, 0.05, mean)
+    post = O.gp_fit(X, y, "matern52", lam, 1.1, 0.05, mean=mean)
+    for call in range(4):
+        Xs = rng.uniform(0, 1, (d, M))
+        mu, var = g.predict(Xs, 0.1 * Xs[0])
+        mu_o, var_o = O.gp_mean_and_var(post, Xs, 0.1 * Xs[0])
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), call
+    # a larger batch in between takes the other kernels and leaves the inverse usable
+    Xb = rng.uniform(0, 1, (d, 40))
+    mu_b, var_b = g.predict(Xb, 0.1 * Xb[0])
+    mu_bo, var_bo = O.gp_mean_and_var(post, Xb, 0.1 * Xb[0])
+    assert np.allclose(mu_b, mu_bo, rtol=0, atol=1e-9) and np.allclose(var_b, var_bo, rtol=0, atol=1e-9)
+    # new hyper-parameters: the cached inverse must not survive
+    g.update(lam * 1.3, 0.9, 0.07, mean)
+    post2 = O.gp_fit(X, y, "matern52", lam * 1.3, 0.9, 0.07, mean=mean)
+    for call in range(3):
+        Xs = rng.uniform(0, 1, (d, M))
+        mu, var = g.predict(Xs, 0.1 * Xs[0])
+        mu_o, var_o = O.gp_mean_and_var(post2, Xs, 0.1 * Xs[0])
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), call
+    # an appended observation likewise
+    xn = rng.uniform(0, 1, (d, 1))
+    g.append(xn, [0.3], 0.1 * xn[0])
+    post3 = O.gp_fit(np.hstack([X, xn]), np.append(y, 0.3), "matern52", lam * 1.3, 0.9, 0.07, mean=np.append(mean, 0.1 * xn[0]))
+    for call in range(3):
+        Xs = rng.uniform(0, 1, (d, M))
+        mu, var = g.predict(Xs, 0.1 * Xs[0])
+        mu_o, var_o = O.gp_mean_and_var(post3, Xs, 0.1 * Xs[0])
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), call
+    g.close()
+
+
+def test_repeated_single_candidate_calls_on_gradient_and_nonstationary_posteriors(api, O):
+    d, n = 3, 300                                            # 1200 augmented rows
+    X, y, dY = make_grad(d, n)
+    lam = np.full(d, 0.45)
+    gg = api.GradGP(X, y, dY, "matern52")
+    gg.update(lam, 1.2, 0.05, 0.1)
+    pg = O.gradient_gp_fit(X, y, dY, "matern52", lam, 1.2, 0.05, 0.1)
+    rng = np.random.default_rng(2)
+    for call in range(4):
+        xs = rng.uniform(0, 1, (d, 1)) if call else X[:, 5:6].copy()
+        mu, var = gg.predict(xs)
+        mu_o, var_o = O.gradient_gp_mean_and_var(pg, xs)
+        assert abs(mu[0] - mu_o[0]) <= 1e-9 and abs(var[0] - var_o[0]) <= 1e-9, call
+    gg.close()
+    N = 1100
+    Xn, yn, _ = make(d, N, 1, seed=9)
+    f_lam, f_amp, f_noise = latent(d)
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                   # noqa: E731
+    gn = api.GibbsGP(Xn, yn)
+    gn.update(ev(f_lam, Xn).T, ev(f_amp, Xn), ev(f_noise, Xn))
+    pn = O.nonstationary_fit(Xn, yn, ev(f_lam, Xn).T, ev(f_amp, Xn), ev(f_noise, Xn))
+    for call in range(4):
+        xs = rng.uniform(0, 1, (d, 2))
+        mu, var = gn.predict(xs, ev(f_lam, xs).T, ev(f_amp, xs))
+        mu_o, var_o = O.nonstationary_mean_and_var(pn, xs, ev(f_lam, xs).T, ev(f_amp, xs))
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), call
+    gn.close()
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
