@@ -183,7 +183,11 @@ int boss_gp_loglike_batch(int device, int kernel, int d, int N, const double* X,
  *   mu = m(X*) + K*' a ; V = C.U' \ K* ; var = k(x*,x*) - sum_i V_ij^2 + 1e-18 ; _clip_var.
  *   Xs d×M, mean_Xs M values m(x*_j) or NULL; mu, var: M each.
  * Returns BOSS_E_NEG_VAR and the first offending index in *bad_index (else -1) when a variance is
- * below -1e-8 (DomainError); mu/var are still written (var unclipped at the offending entries). */
+ * below -1e-8 (DomainError); mu/var are still written (var unclipped at the offending entries).
+ * Calls with one to four candidates — the reference evaluates the acquisition one point at a time
+ * (expected_improvement.jl:75,79) — are served from an explicit inverse factor that the handle builds
+ * on the second such call after an update / append (≈1 ms once, N^2 doubles of extra device memory;
+ * BOSS_WINV_AFTER=0 in the environment disables it). */
 int boss_gp_predict(boss_gp_t* gp, int M, const double* Xs, const double* mean_Xs,
                     double* mu, double* var, long* bad_index);
 
