@@ -197,7 +197,7 @@ struct boss_gp {
     bool gibbs = false;
     double *lamX = nullptr, *ampX = nullptr, *noiseX = nullptr;
     // explicit L⁻ᵀ for calls with one to four candidates (built on the second such call on a factorisation)
-    double* Winv = nullptr;
+    double *Winv = nullptr, *Linv = nullptr;   // L⁻ᵀ (upper) and L⁻¹ (lower)
     bool have_winv = false;
     int few_calls = 0;
 };
@@ -429,6 +429,7 @@ static void gp_release(boss_gp* g) {
         if (p) (void)hipFree(p);
     if (g->host_res) (void)hipHostFree(g->host_res);
     if (g->Winv) (void)hipFree(g->Winv);
+    if (g->Linv) (void)hipFree(g->Linv);
     if (g->lamX) (void)hipFree(g->lamX);
     if (g->ampX) (void)hipFree(g->ampX);
     if (g->noiseX) (void)hipFree(g->noiseX);
@@ -875,7 +876,8 @@ static int gp_grow(boss_gp* g, int Nnew) {
     if (g->avec) (void)hipFree(g->avec);
     g->LT = g->DT2 = g->avec = nullptr;
     if (g->Winv) (void)hipFree(g->Winv);
-    g->Winv = nullptr;
+    if (g->Linv) (void)hipFree(g->Linv);
+    g->Winv = g->Linv = nullptr;
     g->Xraw = nw[0]; g->Xsc = nw[1]; g->y = nw[2]; g->mean = nw[3]; g->A = nw[4]; g->inv16 = nw[5]; g->Dinv = nw[6]; g->Dinv2 = nw[7];
     g->Np = Np2;
     g->nblk = nblk2;
@@ -1220,6 +1222,13 @@ __global__ void scale_cand_kernel(const double* __restrict__ Craw, double* __res
     }
 }
 
+// candidate tiles (of 32) up to which the resident-inverse GEMMs beat the step-by-step substitution (measured at N=4096:
+// 0.19 vs 0.59 ms at 7 tiles, 0.61 vs 0.85 ms at 32, equal at 64, slower beyond)
+static int invgemm_max_tiles() {
+    static const int v = getenv("BOSS_INVGEMM_MAX_TILES") ? atoi(getenv("BOSS_INVGEMM_MAX_TILES")) : 48;
+    return v;
+}
+
 // U = L⁻ᵀ (upper, leading dimension g->ld) by recursive doubling from the 256×256 diagonal inverses; Lw (same shape)
 // is the lower work matrix.  Dinv2 must be current on stream s.
 static void linv_enqueue(boss_gp* g, hipStream_t s, double* U, double* Lw) {
@@ -1256,7 +1265,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
     const int tiles = (cd->M + BN - 1) / BN;
     int rc = ws_reserve(c->csc, sizeof(double) * (size_t)g->d * Mp);
     if (rc) return rc;
-    rc = ws_reserve(c->vscratch, sizeof(double) * (size_t)tiles * BN * g->Np);
+    rc = ws_reserve(c->vscratch, sizeof(double) * (size_t)tiles * BN * g->Np * (for_grad ? 2 : 1));   // gradients: V and W slabs
     if (rc) return rc;
     double* Csc = (double*)c->csc.p;
     if (!g->gibbs)
@@ -1280,22 +1289,25 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         double* R = (double*)c->few.p;                       // residuals [tile][Np][32], start as K*
         double* ssmz = R + (size_t)ftiles * g->Np * 32;
         double* V = (double*)c->vscratch.p;
-        // one to four candidates, repeatedly on the same factorisation: a pass over the explicit L⁻ᵀ (winv_gemv_kernel)
+        // repeated calls with few candidates on one factorisation: from the second call on both inverse factors are
+        // resident — one to four candidates take a single pass over L⁻ᵀ (winv_gemv_kernel), more take two GEMMs
+        // without sequential steps (inv_fwd_kernel / inv_bwd_kernel)
         static const int winv_after = getenv("BOSS_WINV_AFTER") ? atoi(getenv("BOSS_WINV_AFTER")) : 2;
         const size_t winv_lds = sizeof(double) * (size_t)g->Np * WINV_MAX_M;
-        bool use_winv = false;
-        if (!for_grad && cd->M <= WINV_MAX_M && winv_lds <= 144 * 1024 && winv_after > 0) {
-            if (!g->have_winv && ++g->few_calls >= winv_after) {
-                bool ok = g->Winv != nullptr || hipMalloc((void**)&g->Winv, sizeof(double) * (size_t)g->ld * g->Np) == hipSuccess;
-                if (ok && ws_reserve(c->lgB, sizeof(double) * (size_t)g->ld * g->Np) == BOSS_OK) {
-                    linv_enqueue(g, s, g->Winv, (double*)c->lgB.p);
-                    g->have_winv = true;
-                } else {
-                    (void)hipGetLastError();             // no memory for the inverse: stay on the substitution path
-                }
+        if (winv_after > 0 && !g->have_winv && ++g->few_calls >= winv_after) {
+            const size_t bytes = sizeof(double) * (size_t)g->ld * g->Np;
+            bool ok = (g->Winv != nullptr || hipMalloc((void**)&g->Winv, bytes) == hipSuccess) &&
+                      (g->Linv != nullptr || hipMalloc((void**)&g->Linv, bytes) == hipSuccess);
+            if (ok) {
+                linv_enqueue(g, s, g->Winv, g->Linv);
+                g->have_winv = true;
+            } else {
+                (void)hipGetLastError();                 // no memory for the inverses: stay on the substitution path
+                g->few_calls = -(1 << 30);
             }
-            use_winv = g->have_winv;
         }
+        const bool use_winv = g->have_winv && !for_grad && cd->M <= WINV_MAX_M && winv_lds <= 144 * 1024;
+        const bool use_invgemm = g->have_winv && !use_winv && ftiles <= invgemm_max_tiles();   // beyond: the step path is faster
         if (!use_winv) (void)hipMemsetAsync(ssmz, 0, sizeof(double) * 64 * ftiles, s);
         if (g->aug)
             hipLaunchKernelGGL(aug_kstar_kernel, dim3(g->Np / 256, ftiles), dim3(256), aug_lds, s, (const double*)g->Xraw, g->ldx,
@@ -1309,6 +1321,19 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
             hipLaunchKernelGGL(kstar_rows_kernel, dim3(g->Np / 256, ftiles), dim3(256), sizeof(double) * g->d * 32, s,
                                (const double*)g->Xsc, g->Np, g->N, (const double*)Csc, g->d, Mp, g->kernel, g->amp2, R,
                                use_winv ? cd->M : 32);
+        if (use_invgemm) {
+            const int nrb = g->Np / BLK;
+            rc = ws_reserve(c->lgC, sizeof(double) * (size_t)ftiles * nrb * 64);
+            if (rc) return rc;
+            double* ssp = (double*)c->lgC.p;
+            hipLaunchKernelGGL(inv_fwd_kernel<GU>, dim3(nrb, ftiles), dim3(GU::NTHREADS), 0, s, (const double*)g->Linv, g->ld, g->Np,
+                               (const double*)g->A, g->ld, (const double*)R, V, ssp);
+            hipLaunchKernelGGL(inv_fwd_finish_kernel, dim3(ftiles), dim3(256), 0, s, (const double*)ssp, nrb, mean_s_dev, cd->M,
+                               g->amp2, g->aug ? 1 : g->gibbs ? 2 : 0, mu, var);
+            if (g->gibbs) hipLaunchKernelGGL(gibbs_var_kernel, dim3((cd->M + 255) / 256), dim3(256), 0, s, var, camp_dev, cd->M);
+            HIPCHK(hipGetLastError());
+            return BOSS_OK;
+        }
         if (use_winv) {
             double* part = ssmz + 64 * (size_t)ftiles;
             const int mc = cd->M == 1 ? 1 : cd->M == 2 ? 2 : 4;
@@ -1557,7 +1582,14 @@ static int grad_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_de
     double* slabs = (double*)c->vscratch.p;
     static const bool no_few = getenv("BOSS_NO_FEW") && atoi(getenv("BOSS_NO_FEW"));
     static const int few_max_tiles = getenv("BOSS_FEW_MAX_TILES") ? atoi(getenv("BOSS_FEW_MAX_TILES")) : 128;
-    if (tiles <= few_max_tiles && Np >= 4 * PRED_RB && !no_few) {
+    if (tiles <= few_max_tiles && tiles <= invgemm_max_tiles() && Np >= 4 * PRED_RB && !no_few && g->have_winv) {
+        // both inverse factors are resident (repeated calls on this factorisation): W = L⁻ᵀV as one GEMM
+        typedef GemmDirect<4, 1, 2, 2, 8> GU;
+        double* Wsl = slabs + (size_t)tiles * 32 * Np;
+        hipLaunchKernelGGL(inv_bwd_kernel<GU>, dim3(Np / BLK, tiles), dim3(GU::NTHREADS), 0, s, (const double*)g->Winv, g->ld, Np,
+                           (const double*)slabs, Wsl);
+        slabs = Wsl;
+    } else if (tiles <= few_max_tiles && Np >= 4 * PRED_RB && !no_few) {
         // few candidates: the adjoint substitution step by step across the chip (see few_back_* kernels)
         typedef GemmDirect<4, 1, 2, 2, 8> GU;
         for (int ib = Np / PRED_RB - 1; ib >= 0; --ib) {

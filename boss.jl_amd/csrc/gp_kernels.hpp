@@ -694,6 +694,122 @@ __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict
     if (tid < 8) part[(size_t)blockIdx.x * 8 + tid] = ks[tid] + ks[8 + tid] + ks[16 + tid] + ks[24 + tid];
 }
 
+// More than four candidates but fewer than fill the fused kernel (≤ 4096), again repeatedly on one
+// factorisation (multistart refinement: every iteration of HipGradientAM is such a call): with both inverse
+// factors resident the substitutions are plain GEMMs without any sequential step,
+//   inv_fwd_kernel   V = L⁻¹ K*   (A operand = the lower inverse, k range up to the row block),  Σv², v·z partials per row block
+//   inv_bwd_kernel   W = L⁻ᵀ V    (A operand = the upper inverse, k range from the row block)    — the adjoint pass of the gradients
+// on 128×32 tiles, one workgroup per (row block, candidate tile).
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void inv_fwd_kernel(const double* __restrict__ Linv, int ldl, int Np,
+                                                               const double* __restrict__ Afac, int ld,
+                                                               const double* __restrict__ Kst, double* __restrict__ Vslabs,
+                                                               double* __restrict__ ssp) {
+    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32 && GU::WR == 4, "128×32 tiles, four waves stacked along the rows");
+    constexpr int TM = GU::TM, TN = GU::TN;
+    __shared__ double red[2][4][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rb = gridDim.x - 1 - blockIdx.x;               // deepest row blocks first
+    const int r0 = rb * BLK;
+    const double* B = Kst + (size_t)blockIdx.y * Np * 32;
+    double* V = Vslabs + (size_t)blockIdx.y * Np * 32;
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    GU::template run<1>(Linv + r0, ldl, B, 32, r0 + BLK, acc);
+    double ps[TN][4], pz[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ps[n][i] = pz[n][i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = r0 + GU::row_of(wave, m, lane);
+        const double zr = Afac[(size_t)row * ld + Np];
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double v = acc[m][n][i];
+                V[(size_t)row * 32 + GU::col_of(0, n, i, lane)] = v;
+                ps[n][i] = __builtin_fma(v, v, ps[n][i]);
+                pz[n][i] = __builtin_fma(v, zr, pz[n][i]);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double sv = ps[n][i], zv = pz[n][i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                sv += __shfl_xor(sv, off);
+                zv += __shfl_xor(zv, off);
+            }
+            if ((lane & 15) == 0) {
+                const int col = GU::col_of(0, n, i, lane);
+                red[0][wave][col] = sv;
+                red[1][wave][col] = zv;
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int q = threadIdx.x >> 5, col = threadIdx.x & 31;
+        ssp[((size_t)blockIdx.y * gridDim.x + rb) * 64 + threadIdx.x] = red[q][0][col] + red[q][1][col] + red[q][2][col] + red[q][3][col];
+    }
+}
+
+// Σ over the row blocks (fixed order), then μ and σ² as in few_finish_kernel
+__global__ __launch_bounds__(256) void inv_fwd_finish_kernel(const double* __restrict__ ssp, int nrb, const double* __restrict__ mean_s,
+                                                             int M, double amp2, int mode, double* __restrict__ mu,
+                                                             double* __restrict__ var) {
+    __shared__ double red[4][64];
+    const int tid = threadIdx.x, q = tid & 63, grp = tid >> 6;
+    const double* p = ssp + (size_t)blockIdx.x * nrb * 64;
+    double a = 0.0;
+    for (int rb = grp; rb < nrb; rb += 4) a += p[(size_t)rb * 64 + q];
+    red[grp][q] = a;
+    __syncthreads();
+    if (tid < 32) {
+        const int j = blockIdx.x * 32 + tid;
+        if (j < M) {
+            const double sv = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            const double zv = (red[0][32 + tid] + red[1][32 + tid]) + (red[2][32 + tid] + red[3][32 + tid]);
+            mu[j] = (mean_s ? mean_s[j] : 0.0) + zv;
+            var[j] = mode == 2 ? -sv : mode == 1 ? fmax(0.0, amp2 - sv) : amp2 - sv + PREDICT_JITTER;
+        }
+    }
+}
+
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void inv_bwd_kernel(const double* __restrict__ Uinv, int ldu, int Np,
+                                                               const double* __restrict__ Vslabs, double* __restrict__ Wslabs) {
+    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
+    constexpr int TM = GU::TM, TN = GU::TN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = blockIdx.x * BLK;                         // block 0 is the deepest here
+    const double* V = Vslabs + (size_t)blockIdx.y * Np * 32;
+    double* W = Wslabs + (size_t)blockIdx.y * Np * 32;
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    GU::template run<1>(Uinv + r0 + (size_t)r0 * ldu, ldu, V + (size_t)r0 * 32, 32, Np - r0, acc);
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = r0 + GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) W[(size_t)row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
+    }
+}
+
 // mode: 0 plain (σ² = α² − Σv² + 1e-18), 1 gradient observations (max(0, α² − Σv²)), 2 nonstationary (−Σv²; gibbs_var_kernel follows)
 __global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restrict__ part, int nwg, int M,
                                                           const double* __restrict__ mean_s, double amp2, int mode,

@@ -942,7 +942,7 @@ def test_few_candidates_path(api, O, N, M):
     g.close()
 
 
-@pytest.mark.parametrize("N,M", [(1024, 1), (1300, 3), (2048, 4), (4096, 1)])
+@pytest.mark.parametrize("N,M", [(1024, 1), (1300, 3), (2048, 4), (4096, 1), (1024, 20), (1300, 33), (2048, 200)])
 def test_repeated_few_candidate_calls_use_the_explicit_inverse(api, O, N, M):
     """One to four candidates per call, many calls per posterior (the reference's `acq.(eachcol(xs))` pattern): from
     the second call on a factorisation the handle predicts through the explicit L⁻ᵀ.  Every call agrees with the
@@ -961,6 +961,17 @@ def test_repeated_few_candidate_calls_use_the_explicit_inverse(api, O, N, M):
         mu, var = g.predict(Xs, 0.1 * Xs[0])
         mu_o, var_o = O.gp_mean_and_var(post, Xs, 0.1 * Xs[0])
         assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), call
+    # gradients on the resident inverses (forward and adjoint passes as GEMMs), repeatedly
+    for call in range(3):
+        Xs = rng.uniform(0, 1, (d, M))
+        mu, var, dmu, dvar = g.predict_grad(Xs, 0.1 * Xs[0], np.vstack([np.full(M, 0.1), np.zeros((d - 1, M))]))
+        mu_o, var_o, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs, 0.1 * Xs[0], np.vstack([np.full(M, 0.1), np.zeros((d - 1, M))]))
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, O.clip_var(var_o), rtol=0, atol=1e-9), call
+        assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8 * (1 + np.abs(dmu_o).max())), call
+        assert np.allclose(dvar, dvar_o, rtol=0, atol=1e-8 * (1 + np.abs(dvar_o).max())), call
+    _, cov = g.predict_cov(Xs, 0.1 * Xs[0])
+    _, cov_o = O.gp_mean_and_cov(post, Xs, 0.1 * Xs[0])
+    assert np.allclose(cov, cov_o, rtol=0, atol=1e-9)
     # a larger batch in between takes the other kernels and leaves the inverse usable
     Xb = rng.uniform(0, 1, (d, 40))
     mu_b, var_b = g.predict(Xb, 0.1 * Xb[0])
