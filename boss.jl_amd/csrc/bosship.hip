@@ -50,6 +50,18 @@ static int fail(int code, const std::string& msg) {
 constexpr size_t PINNED_BYTES = 64 * 1024, PINNED_UP_OFF = 4096, PINNED_UP_BYTES = 32 * 1024, PINNED_DOWN_OFF = 36 * 1024,
                  PINNED_DOWN_BYTES = 28 * 1024;
 
+// every device allocation goes through here; BOSS_POISON_ALLOC=1 (tests) fills new memory with NaN bit patterns so that
+// reads of never-written memory show up instead of passing on the zeros a fresh process happens to get
+static hipError_t dev_malloc(void** p, size_t bytes) {
+    static const bool poison = getenv("BOSS_POISON_ALLOC") && atoi(getenv("BOSS_POISON_ALLOC"));
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison) {
+        (void)hipMemset(*p, 0xff, bytes);                    // null stream: the library's streams do not wait for it ...
+        (void)hipDeviceSynchronize();                        // ... so finish it before anything else touches the block
+    }
+    return e;
+}
+
 struct Workspace {
     void* p = nullptr;
     size_t bytes = 0;
@@ -135,7 +147,7 @@ static int ws_reserve(Workspace& w, size_t bytes) {
     if (w.p) (void)hipFree(w.p);
     w.p = nullptr;
     w.bytes = 0;
-    HIPCHK(hipMalloc(&w.p, bytes));
+    HIPCHK(dev_malloc(&w.p, bytes));
     w.bytes = bytes;
     return BOSS_OK;
 }
@@ -477,7 +489,7 @@ static int gp_create_common(int device, int kernel, int d, int npts, int N, cons
     const size_t Np = g->Np, ldx = g->ldx;
 #define GALLOC(ptr, bytes)                                        \
     do {                                                          \
-        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));       \
+        hipError_t e_ = dev_malloc((void**)&(ptr), (bytes));       \
         if (e_ != hipSuccess) {                                   \
             gp_release(g);                                        \
             return fail(BOSS_E_ALLOC, "device allocation failed"); \
@@ -565,9 +577,9 @@ extern "C" int boss_ngp_create(int device, int d, int N, const double* X, const 
     g->gibbs = true;
     g->kernel = KERN_GIBBS;
     const size_t Np = g->Np;
-    if (hipMalloc((void**)&g->lamX, sizeof(double) * d * Np) != hipSuccess ||
-        hipMalloc((void**)&g->ampX, sizeof(double) * Np) != hipSuccess ||
-        hipMalloc((void**)&g->noiseX, sizeof(double) * Np) != hipSuccess) {
+    if (dev_malloc((void**)&g->lamX, sizeof(double) * d * Np) != hipSuccess ||
+        dev_malloc((void**)&g->ampX, sizeof(double) * Np) != hipSuccess ||
+        dev_malloc((void**)&g->noiseX, sizeof(double) * Np) != hipSuccess) {
         gp_release(g);
         *out = nullptr;
         return fail(BOSS_E_ALLOC, "device allocation failed");
@@ -850,7 +862,7 @@ static int gp_grow(boss_gp* g, int Nnew) {
                              szA, sizeof(double) * nblk2 * 8 * 256, sizeof(double) * nblk2 * BLK * BLK,
                              sizeof(double) * (size_t)Np2 * PRED_RB};
     for (int i = 0; i < 8; ++i)
-        if (hipMalloc((void**)&nw[i], bytes[i]) != hipSuccess) {
+        if (dev_malloc((void**)&nw[i], bytes[i]) != hipSuccess) {
             for (int j = 0; j < i; ++j) (void)hipFree(nw[j]);
             return fail(BOSS_E_ALLOC, "device allocation failed while growing the posterior handle");
         }
@@ -920,6 +932,7 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "append needs a fitted handle (its hyper-parameters are reused)");
     hipStream_t s = c->stream;
     const int d = g->d, N0 = g->N, N1 = N0 + n;
+    const int Np_before = g->Np;
     int rc = gp_grow(g, N1);
     if (rc) return rc;
     g->fitted = false;
@@ -940,7 +953,9 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
         HIPCHK(hipStreamSynchronize(s));       // staging buffers go out of scope
     }
     g->N = N1;
-    const int kb0 = N0 / BLK, kb1 = (N1 - 1) / BLK;
+    // block rows to (re)build: those holding new observations and, when the storage has just grown, the pure padding
+    // block rows behind them as well (identity blocks of the factor and their inverses: the new arrays are uninitialised)
+    const int kb0 = N0 / BLK, kb1 = (g->Np != Np_before) ? g->nblk - 1 : (N1 - 1) / BLK;
     if (kb1 - kb0 + 1 > 4 || kb1 - kb0 + 1 >= g->nblk) {
         // most of the matrix is new: a plain re-factorisation is cheaper than block-row sweeps
         rc = factor_enqueue(g);
@@ -1160,7 +1175,7 @@ extern "C" int boss_cand_create(int device, int d, int M, const double* Xs, boss
     cd->d = d;
     cd->M = M;
     cd->Mp = round_up(M, 64);
-    if (hipMalloc((void**)&cd->Craw, sizeof(double) * d * cd->Mp) != hipSuccess) {
+    if (dev_malloc((void**)&cd->Craw, sizeof(double) * d * cd->Mp) != hipSuccess) {
         delete cd;
         return fail(BOSS_E_ALLOC, "device allocation failed");
     }
@@ -1243,7 +1258,9 @@ static void linv_enqueue(boss_gp* g, hipStream_t s, double* U, double* Lw) {
 
 // enqueue μ/σ² (unclipped) of one posterior at resident candidates into device arrays mu, var (length ≥ M)
 static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_dev, double* mu, double* var,
-                           bool for_grad = false, const double* clam_dev = nullptr, const double* camp_dev = nullptr) {
+                           bool for_grad = false, const double* clam_dev = nullptr, const double* camp_dev = nullptr,
+                           bool need_v = false) {
+    // need_v: the caller reads V = L⁻¹K* from the slab scratch afterwards (covariances); for_grad implies it
     Ctx* c = g->ctx;
     hipStream_t s = c->stream;
     if (!g->fitted) return fail(BOSS_E_NOT_FITTED, "handle has no valid factorisation");
@@ -1296,8 +1313,8 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
         const size_t winv_lds = sizeof(double) * (size_t)g->Np * WINV_MAX_M;
         if (winv_after > 0 && !g->have_winv && ++g->few_calls >= winv_after) {
             const size_t bytes = sizeof(double) * (size_t)g->ld * g->Np;
-            bool ok = (g->Winv != nullptr || hipMalloc((void**)&g->Winv, bytes) == hipSuccess) &&
-                      (g->Linv != nullptr || hipMalloc((void**)&g->Linv, bytes) == hipSuccess);
+            bool ok = (g->Winv != nullptr || dev_malloc((void**)&g->Winv, bytes) == hipSuccess) &&
+                      (g->Linv != nullptr || dev_malloc((void**)&g->Linv, bytes) == hipSuccess);
             if (ok) {
                 linv_enqueue(g, s, g->Winv, g->Linv);
                 g->have_winv = true;
@@ -1306,7 +1323,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
                 g->few_calls = -(1 << 30);
             }
         }
-        const bool use_winv = g->have_winv && !for_grad && cd->M <= WINV_MAX_M && winv_lds <= 144 * 1024;
+        const bool use_winv = g->have_winv && !for_grad && !need_v && cd->M <= WINV_MAX_M && winv_lds <= 144 * 1024;
         const bool use_invgemm = g->have_winv && !use_winv && ftiles <= invgemm_max_tiles();   // beyond: the step path is faster
         if (!use_winv) (void)hipMemsetAsync(ssmz, 0, sizeof(double) * 64 * ftiles, s);
         if (g->aug)
@@ -1545,9 +1562,9 @@ static int grad_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_de
     const size_t glds = sizeof(double) * ((size_t)d * GRAD_CHUNK + GRAD_CHUNK + 8 * 2 * (GRAD_MAX_D + 1) * 32);
     if (glds > 150 * 1024) return fail(BOSS_E_INVALID, "x_dim too large for the gradient kernel's LDS staging");
     if (!g->LT) {
-        if (hipMalloc((void**)&g->LT, sizeof(double) * (size_t)g->ld * Np) != hipSuccess ||
-            hipMalloc((void**)&g->DT2, sizeof(double) * (size_t)Np * PRED_RB) != hipSuccess ||
-            hipMalloc((void**)&g->avec, sizeof(double) * (size_t)Np * 2) != hipSuccess) {
+        if (dev_malloc((void**)&g->LT, sizeof(double) * (size_t)g->ld * Np) != hipSuccess ||
+            dev_malloc((void**)&g->DT2, sizeof(double) * (size_t)Np * PRED_RB) != hipSuccess ||
+            dev_malloc((void**)&g->avec, sizeof(double) * (size_t)Np * 2) != hipSuccess) {
             if (g->LT) (void)hipFree(g->LT);
             if (g->DT2) (void)hipFree(g->DT2);
             g->LT = g->DT2 = g->avec = nullptr;
@@ -1768,7 +1785,7 @@ extern "C" int boss_gp_predict_cov(boss_gp_t* g, int M, const double* Xs, const 
     int rc = boss_cand_create(c->device, g->d, M, Xs, &cd);
     if (rc) return rc;
     double* dev = nullptr;   // mu | var | mean | bad | cov
-    if (hipMalloc((void**)&dev, sizeof(double) * (3 * (size_t)M + 2 + (size_t)M * M)) != hipSuccess) {
+    if (dev_malloc((void**)&dev, sizeof(double) * (3 * (size_t)M + 2 + (size_t)M * M)) != hipSuccess) {
         boss_cand_free(cd);
         return fail(BOSS_E_ALLOC, "device allocation failed");
     }
@@ -1783,7 +1800,7 @@ extern "C" int boss_gp_predict_cov(boss_gp_t* g, int M, const double* Xs, const 
     };
     if (mean_Xs) (void)hipMemcpyAsync(dmean, mean_Xs, sizeof(double) * M, hipMemcpyHostToDevice, s);
     (void)hipMemsetAsync(dbad, 0xff, sizeof(unsigned long long), s);
-    rc = predict_enqueue(g, cd, mean_Xs ? dmean : nullptr, dmu, dvar);   // leaves V in the slab scratch, Csc scaled
+    rc = predict_enqueue(g, cd, mean_Xs ? dmean : nullptr, dmu, dvar, false, nullptr, nullptr, true);   // leaves V in the slab scratch, Csc scaled
     if (rc) {
         cleanup();
         return rc;
@@ -2036,7 +2053,7 @@ static int track_rebuild(boss_track* t, const boss_cand* cd) {
     if (Ncap > t->Ncap) {
         if (t->V) (void)hipFree(t->V);
         t->V = nullptr;
-        if (hipMalloc((void**)&t->V, sizeof(double) * (size_t)t->tiles * Ncap * 32) != hipSuccess) {
+        if (dev_malloc((void**)&t->V, sizeof(double) * (size_t)t->tiles * Ncap * 32) != hipSuccess) {
             (void)hipGetLastError();
             return fail(BOSS_E_ALLOC, "device allocation failed (tracked V slabs)");
         }
@@ -2069,10 +2086,10 @@ extern "C" int boss_track_create(boss_gp_t* g, const boss_cand_t* cand, const do
     t->M = cand->M;
     t->Mp = cand->Mp;
     t->tiles = (cand->M + 31) / 32;
-    if (hipMalloc((void**)&t->Csc, sizeof(double) * (size_t)t->d * t->Mp) != hipSuccess ||
-        hipMalloc((void**)&t->mu, sizeof(double) * t->M) != hipSuccess ||
-        hipMalloc((void**)&t->var, sizeof(double) * t->M) != hipSuccess ||
-        hipMalloc((void**)&t->mean, sizeof(double) * t->M) != hipSuccess) {
+    if (dev_malloc((void**)&t->Csc, sizeof(double) * (size_t)t->d * t->Mp) != hipSuccess ||
+        dev_malloc((void**)&t->mu, sizeof(double) * t->M) != hipSuccess ||
+        dev_malloc((void**)&t->var, sizeof(double) * t->M) != hipSuccess ||
+        dev_malloc((void**)&t->mean, sizeof(double) * t->M) != hipSuccess) {
         (void)hipGetLastError();
         track_release(t);
         return fail(BOSS_E_ALLOC, "device allocation failed");
@@ -2213,7 +2230,7 @@ extern "C" int boss_bench_mfma_f64(int device, int iters, double* tflops_out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     const int blocks = prop.multiProcessorCount;   // one 4-wave workgroup per CU = one wave per SIMD
     double* sink;
-    HIPCHK(hipMalloc((void**)&sink, 8));
+    HIPCHK(dev_malloc((void**)&sink, 8));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

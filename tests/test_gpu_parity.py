@@ -514,7 +514,7 @@ def test_ei_from_moments_and_shard_modes(api, O):
 
 
 @pytest.mark.parametrize("N0,steps", [(5, [1, 1, 3]), (100, [1]), (127, [2]), (128, [1]), (130, [1, 1, 1]), (255, [1, 130]),
-                                      (300, [40, 100]), (256, [600]), (640, [1, 1])])
+                                      (300, [40, 100]), (256, [600]), (640, [1, 1]), (255, [33]), (250, [7, 300])])
 def test_block_cholesky_append(api, O, N0, steps):
     """boss_gp_append == a fresh fit of the augmented data (augment_dataset! + model_posterior with
     unchanged hyper-parameters, problem.jl:191-198 / batch.jl:32-38): logpdf, factor, mean, variance."""
@@ -969,9 +969,11 @@ def test_repeated_few_candidate_calls_use_the_explicit_inverse(api, O, N, M):
         assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, O.clip_var(var_o), rtol=0, atol=1e-9), call
         assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8 * (1 + np.abs(dmu_o).max())), call
         assert np.allclose(dvar, dvar_o, rtol=0, atol=1e-8 * (1 + np.abs(dvar_o).max())), call
-    _, cov = g.predict_cov(Xs, 0.1 * Xs[0])
-    _, cov_o = O.gp_mean_and_cov(post, Xs, 0.1 * Xs[0])
-    assert np.allclose(cov, cov_o, rtol=0, atol=1e-9)
+    for call in range(2):                                    # covariances need V itself: never the one-pass kernel
+        Xs = rng.uniform(0, 1, (d, M))
+        _, cov = g.predict_cov(Xs, 0.1 * Xs[0])
+        _, cov_o = O.gp_mean_and_cov(post, Xs, 0.1 * Xs[0])
+        assert np.allclose(cov, cov_o, rtol=0, atol=1e-9), call
     # a larger batch in between takes the other kernels and leaves the inverse usable
     Xb = rng.uniform(0, 1, (d, 40))
     mu_b, var_b = g.predict(Xb, 0.1 * Xb[0])
@@ -1366,3 +1368,16 @@ def test_nonstationary_gp_full_size(api, O):
     mu_o, var_o = O.nonstationary_mean_and_var(post, Xs[:, :512], lamS[:, :512], ampS[:512])
     assert np.allclose(mu[:512], mu_o, rtol=0, atol=1e-9) and np.allclose(var[:512], var_o, rtol=0, atol=1e-9)
     g.close()
+
+
+def test_random_call_sequences_on_poisoned_allocations():
+    """tools/fuzz.py — random shapes and random sequences of update / predict / gradients / covariance / append /
+    likelihood gradient on one handle, each result checked against the oracle — with every new device allocation
+    filled with NaN patterns (BOSS_POISON_ALLOC=1): nothing may depend on the zeros of fresh memory."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BOSS_POISON_ALLOC="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz.py"), "30", "5"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "30 cases passed" in r.stdout
