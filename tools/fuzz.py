@@ -42,8 +42,9 @@ for case in range(first, ncases):
     assert abs(lp - post.logpdf) <= tol * (1 + abs(post.logpdf)), ("logpdf", case)
     ops = []
     M = 0
+    track = tcand = tXs = None
     for step in range(int(rng.integers(4, 10))):
-        op = rng.choice(["predict", "predict", "predict", "grad", "cov", "append", "update", "llgrad"])
+        op = rng.choice(["predict", "predict", "predict", "grad", "cov", "append", "append", "update", "llgrad", "track", "acq", "acqgrad"])
         ops.append(op)
         try:
             if op == "predict":
@@ -85,6 +86,44 @@ for case in range(first, ncases):
                 lp = g.update(lam, amp, sig, mfun(X))
                 post = O.gp_fit(X, y, kern, lam, amp, sig, mean=mfun(X), discrete=disc)
                 e = abs(lp - post.logpdf) / (1 + abs(post.logpdf))
+                if track is not None:                      # a track belongs to one set of hyper-parameters
+                    track.close()
+                    track = None
+            elif op == "track":
+                # tracked candidates (resident V slabs): created once, must follow every later append / update
+                if track is None:
+                    M = int(rng.choice([1, 31, 64, 100, 300]))
+                    tXs = np.asfortranarray(rng.uniform(0, scale, (d, M)))
+                    tcand = api.Candidates(tXs)
+                    track = api.Track(g, tcand, mfun(tXs))
+                mu, var = track.moments()
+                mu_o, var_o = O.gp_mean_and_var(post, tXs, mfun(tXs), clip=False)
+                e = max(np.abs(mu - mu_o).max() / (1 + np.abs(mu_o).max()), np.abs(var - var_o).max() / amp ** 2)
+                if rng.random() < 0.5:
+                    acq, am, mx = api.acq_ei_tracks([[track]], [1.0], None, float(y.max()), None)
+                    want = O.ei_acquisition([post], tXs, [1.0], None, float(y.max()), means_s=None if not use_mean else [mfun(tXs)],
+                                            constrained=False)
+                    e = max(e, np.abs(acq - want).max())
+            elif op == "acq":
+                M = int(rng.choice([1, 4, 33, 200, 1100]))
+                Xs = np.asfortranarray(rng.uniform(-0.05 * scale, 1.05 * scale, (d, M)))
+                mask = O.in_bounds(Xs, np.zeros(d), np.full(d, scale))
+                ms = None if not use_mean else mfun(Xs).reshape(1, 1, M)
+                acq, am, mx = api.acq_ei([[g]], api.Candidates(Xs), [1.0], [float(y.max()) + 0.5], float(np.median(y)), mask, ms)
+                want = O.ei_acquisition([post], Xs, [1.0], [float(y.max()) + 0.5], float(np.median(y)), valid_mask=mask,
+                                        means_s=None if not use_mean else [mfun(Xs)])
+                e = np.abs(acq - want).max()
+                assert am == int(np.argmax(acq)), ("argmax", case)
+            elif op == "acqgrad":
+                M = int(rng.choice([1, 3, 40, 224]))
+                Xs = np.asfortranarray(rng.uniform(0, scale, (d, M)))
+                mg = np.vstack([np.full(M, -0.1), np.zeros((d - 1, M))]) if use_mean else None
+                acq, dacq = api.acq_ei_grad([g], Xs, [1.0], None, float(np.median(y)), None,
+                                            None if not use_mean else mfun(Xs).reshape(1, M), None if mg is None else mg.reshape(1, d, M))
+                want, dwant = O.ei_acquisition_grad([post], Xs, [1.0], None, float(np.median(y)),
+                                                    means_s=None if not use_mean else [mfun(Xs)],
+                                                    mean_grads_s=None if mg is None else [mg])
+                e = max(np.abs(acq - want).max(), np.abs(dacq - dwant).max() / (1 + np.abs(dwant).max()) / 10)
             else:
                 if d > 32:
                     continue
@@ -119,6 +158,8 @@ for case in range(first, ncases):
         if e > tol:
             print(f"CASE {case} d={d} N={N} {kern} disc={disc is not None} mean={use_mean} ops={ops}: error {e:.3e} > tol {tol:.1e}", flush=True)
             sys.exit(1)
+    if track is not None:
+        track.close()
     g.close()
     if case % 5 == 4:
         print(f"  {case + 1} cases ok, worst error/tolerance so far {worst:.2e}, {time.time() - t_start:.0f} s", flush=True)
