@@ -44,7 +44,8 @@ for case in range(first, ncases):
     M = 0
     track = tcand = tXs = None
     for step in range(int(rng.integers(4, 10))):
-        op = rng.choice(["predict", "predict", "predict", "grad", "cov", "append", "append", "update", "llgrad", "track", "acq", "acqgrad"])
+        op = rng.choice(["predict", "predict", "predict", "grad", "cov", "append", "append", "update", "llgrad", "track", "acq", "acqgrad",
+                         "batch"])
         ops.append(op)
         try:
             if op == "predict":
@@ -89,6 +90,20 @@ for case in range(first, ncases):
                 if track is not None:                      # a track belongs to one set of hyper-parameters
                     track.close()
                     track = None
+            elif op == "batch":
+                # batched likelihoods on the current data (boss_gp_loglike_batch): S hyper-parameter sets, one of them
+                # possibly not positive definite (duplicated data without noise cannot be made here: use a huge lengthscale)
+                S = int(rng.choice([1, 2, 3, 5, 8, 17, 40])) if X.shape[1] <= 1100 else int(rng.choice([1, 3, 5]))
+                lams = rng.uniform(0.3, 0.9, (d, S)) * scale
+                amps, sigs = rng.uniform(0.7, 1.5, S), rng.uniform(0.03, 0.1, S)
+                per_set_mean = use_mean and rng.random() < 0.5
+                mX = None if not use_mean else (np.stack([mfun(X) + 0.01 * k for k in range(S)]) if per_set_mean else mfun(X))
+                ll, st = api.loglike_batch(X, y, kern, lams, amps, sigs, mX, disc)
+                e = 0.0
+                for k in range(S):
+                    mk = None if mX is None else (mX[k] if per_set_mean else mX)
+                    want = O.gp_data_loglike_slice(X, y, kern, lams[:, k], amps[k], sigs[k], mean=mk, discrete=disc)
+                    e = max(e, abs(ll[k] - want) / (1 + abs(want)))
             elif op == "track":
                 # tracked candidates (resident V slabs): created once, must follow every later append / update
                 if track is None:
