@@ -60,7 +60,9 @@ def pmc_traffic(kernel_substr):
     global PMC_SUMMARY
     import glob
     try:
-        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+        import re
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")),
+                       key=lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))])   # r01_v10 after r01_v5
         PMC_SUMMARY = os.path.relpath(paths[-1], ROOT)
         d = json.load(open(paths[-1]))
         for k, v in d.items():
@@ -110,6 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the next_rows measurements (counter-collection passes)")
     args = ap.parse_args()
 
     import torch
@@ -219,7 +222,7 @@ def main():
 
     # ---- SURVEY §8f rows built beyond the headline path (rank 0, N=1 only; a fraction of a second)
     extras = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         gp.update(lam, 1.0, 0.05)
         t0 = time.perf_counter()
         for _ in range(3):
