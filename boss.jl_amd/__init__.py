@@ -13,6 +13,6 @@ from .problem import (BossOptions, BossProblem, Dirac, Domain, ExperimentData, E
 from .model import HipGaussianProcess, HipGPParams, average_mean  # noqa: F401,E402
 from .gradient_gp import (GradientData, HipGradientGaussianProcess, HipGradientGPParams,  # noqa: F401,E402
                           join_gradient_slices)
-from .nonstationary import HipNonstationaryGP  # noqa: F401,E402
+from .nonstationary import HipNonstationaryGP, HipParametrizedGP, stack_latents  # noqa: F401,E402
 from .fitter import HipBatchedMAP, HipGradientMAP, HipSampleOptMAP, MAPParams  # noqa: F401,E402
 from .maximizer import HipBatchAM, HipGradientAM, HipSequentialBatchAM  # noqa: F401,E402

@@ -8,6 +8,7 @@ Gibbs Gram matrix, Cholesky, likelihood, prediction — runs on the device (`bos
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -18,7 +19,109 @@ from .problem import ExperimentData
 
 
 def _cols(f: Callable, X: np.ndarray) -> np.ndarray:
+    """f at every column of X: rows = points.  Closures flagged `vectorized` take the whole d×M matrix at once
+    (the ParametrizedGP posteriors below: one device call for all points)."""
+    if getattr(f, "vectorized", False):
+        return np.asarray(f(X), float)
     return np.array([np.asarray(f(X[:, j]), float) for j in range(X.shape[1])])
+
+
+# ---------------------------------------------------------------------------------------------
+# ParametrizedGP (src/models/nonstationary_gp/parametrized_gp.jl): the latent model of one hyper-parameter
+# of the NonstationaryGP — a zero-mean, unit-amplitude GP over the data points whose (whitened) outputs are the
+# parameters; its posterior mean, pushed through Normal-cdf -> target quantile -> activation, is the value of
+# the hyper-parameter at x.
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class HipParametrizedGPParams:
+    """ParametrizedGPParams(X, μ, L, yϵ, λ) (parametrized_gp.jl:64-76)."""
+    X: np.ndarray
+    mu: np.ndarray
+    L: np.ndarray
+    yeps: np.ndarray
+    lengthscale: np.ndarray
+
+
+@dataclass
+class HipParametrizedGP:
+    """ParametrizedGP(kernel, lengthscale_prior, target_dist, act_func, noise_std) (:39-47).  The reference requires a
+    Dirac lengthscale prior (:193): `lengthscale` holds its values.  `target_dist`: None or anything with `.ppf(u)`
+    (a frozen scipy.stats distribution); `act_func` must accept arrays."""
+    lengthscale: Sequence[float]
+    kernel: str = "matern32"
+    target_dist: object = None
+    act_func: Callable = staticmethod(lambda z: z)
+    noise_std: float = 0.0
+    device: int = 0
+
+    def transform(self, y):
+        """construct_variable_transform (:122-134) then act_func: z = quantile(target, cdf(Normal(0,1), y))."""
+        y = np.asarray(y, float)
+        if self.target_dist is not None:
+            from scipy.special import ndtr
+            y = self.target_dist.ppf(ndtr(y))
+        return self.act_func(y)
+
+    def params_sampler(self, data: ExperimentData):
+        """_params_sampler (:191-215): L = chol of the prior covariance at the data points (finite_param_gp, :136-158),
+        yϵ ~ N(0, I)."""
+        lam = np.asarray(self.lengthscale, float)
+        n = data.X.shape[1]
+        g = api.GP(data.X, np.zeros(n), self.kernel, None, self.device)
+        try:
+            g.update(lam, 1.0, self.noise_std)
+            L, _ = g.factor()
+        finally:
+            g.close()
+        mu = np.zeros(n)
+
+        def sample(rng):
+            return HipParametrizedGPParams(data.X, mu, L, rng.standard_normal(n), lam)
+        return sample
+
+    def params_loglike(self, data: ExperimentData = None):
+        """params_loglike (:160-189): logpdf(MvNormal(0, I), yϵ)."""
+        return lambda p: float(-0.5 * (p.yeps @ p.yeps) - 0.5 * len(p.yeps) * math.log(2.0 * math.pi))
+
+    def model_posterior(self, params: HipParametrizedGPParams, data: ExperimentData = None):
+        """model_posterior (:90-106): x -> act(ft(mean of the GP posterior conditioned on y = L yϵ + μ)).  The returned
+        closure takes one point or a d×M matrix (one device call); `.close()` releases the handle."""
+        y = params.L @ params.yeps + params.mu
+        g = api.GP(params.X, y, self.kernel, None, self.device)
+        g.update(params.lengthscale, 1.0, self.noise_std)
+
+        def post(x):
+            x = np.asarray(x, float)
+            m, _ = g.predict(x[:, None] if x.ndim == 1 else x)
+            z = self.transform(m)
+            return float(z[0]) if x.ndim == 1 else z
+        post.vectorized = True
+        post.close = g.close
+        return post
+
+    def model_posterior_lookup(self, params: HipParametrizedGPParams, data: ExperimentData = None):
+        """model_posterior_lookup (:108-120): the values at the data points only, no kernel matrix."""
+        vals = self.transform(params.L @ params.yeps + params.mu)
+        table = {tuple(params.X[:, j]): float(vals[j]) for j in range(params.X.shape[1])}
+
+        def post(x):
+            x = np.asarray(x, float)
+            if x.ndim == 1:
+                return table[tuple(x)]
+            return np.array([table[tuple(x[:, j])] for j in range(x.shape[1])])
+        post.vectorized = True
+        return post
+
+
+def stack_latents(posts: Sequence[Callable]) -> Callable:
+    """x -> apply.(posts, Ref(x)) (nonstationary_gp.jl:209-212): the x_dim latent lengthscale models of one output as
+    one closure returning a d-vector (or M×d for a matrix of points)."""
+    def f(x):
+        x = np.asarray(x, float)
+        cols = [np.asarray(p(x), float) for p in posts]
+        return np.array(cols) if x.ndim == 1 else np.stack(cols, axis=1)
+    f.vectorized = all(getattr(p, "vectorized", False) for p in posts)
+    return f
 
 
 @dataclass

@@ -1381,3 +1381,55 @@ def test_random_call_sequences_on_poisoned_allocations():
                        timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "30 cases passed" in r.stdout
+
+
+def test_nonstationary_gp_with_parametrized_gp_latents(api, O):
+    """The reference's full NonstationaryGP: every lengthscale is a ParametrizedGP (parametrized_gp.jl) — a latent GP over
+    the data whose whitened outputs are parameters, pushed through Normal-cdf -> target quantile -> activation.  The
+    latent posteriors are evaluated on the device for all points at once; the result must equal the oracle's chain."""
+    import boss_jl_amd as B
+    from scipy import stats
+    from scipy.special import ndtr
+    rng = np.random.default_rng(40)
+    d, N, M = 2, 120, 50
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.sin(5 * X[0:1]) + X[1:2]
+    Xs = np.asfortranarray(rng.uniform(0, 1, (d, M)))
+    data = B.ExperimentData(X, Y)
+    act = [lambda z: 0.1 + 0.9 * z, lambda z: 0.2 + 0.5 * z]
+    latents = [B.HipParametrizedGP([0.3, 0.3], "matern32", stats.beta(2, 3), act[k], 1e-2) for k in range(d)]
+    params = [latents[k].params_sampler(data)(rng) for k in range(d)]
+    # oracle chain for one latent: prior Cholesky, de-whitening, posterior mean, transform
+    def latent_oracle(k, Z):
+        prior = O.gp_fit(X, np.zeros(N), "matern32", [0.3, 0.3], 1.0, 1e-2)
+        assert np.abs(prior.L - params[k].L).max() <= 1e-10
+        yk = prior.L @ params[k].yeps
+        post = O.gp_fit(X, yk, "matern32", [0.3, 0.3], 1.0, 1e-2)
+        m = O.gp_mean_and_var(post, Z)[0]
+        return act[k](stats.beta(2, 3).ppf(ndtr(m)))
+    posts = [latents[k].model_posterior(params[k], data) for k in range(d)]
+    look = [latents[k].model_posterior_lookup(params[k], data) for k in range(d)]
+    for k in range(d):
+        want = latent_oracle(k, Xs)
+        assert np.allclose(posts[k](Xs), want, rtol=0, atol=1e-7)
+        assert abs(posts[k](Xs[:, 3]) - want[3]) <= 1e-7
+        yk = params[k].L @ params[k].yeps                                         # lookup: transform of the de-whitened outputs themselves
+        assert np.allclose(look[k](X), act[k](stats.beta(2, 3).ppf(ndtr(yk))), rtol=0, atol=1e-12)
+        assert abs(latents[k].params_loglike()(params[k]) - stats.norm.logpdf(params[k].yeps).sum()) <= 1e-10
+    f_lam = B.stack_latents(posts)
+    model = B.HipNonstationaryGP([f_lam], [lambda x: 1.1], [lambda x: 0.05])
+    post = model.model_posterior(data)[0]
+    lamX = np.stack([latent_oracle(k, X) for k in range(d)])
+    lamS = np.stack([latent_oracle(k, Xs) for k in range(d)])
+    op = O.nonstationary_fit(X, Y[0], lamX, np.full(N, 1.1), np.full(N, 0.05))
+    mu_o, var_o = O.nonstationary_mean_and_var(op, Xs, lamS, np.full(M, 1.1))
+    mu, var = post.mean_and_var(Xs)
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-6) and np.allclose(var, var_o, rtol=0, atol=1e-6)
+    # likelihood with the cheap lookup latents (data_loglike_slice uses finite_nongp_lookup, nonstationary_gp.jl:237-245)
+    model_l = B.HipNonstationaryGP([B.stack_latents(look)], [lambda x: 1.1], [lambda x: 0.05])
+    lamL = np.stack([act[k](stats.beta(2, 3).ppf(ndtr(params[k].L @ params[k].yeps))) for k in range(d)])
+    ll = model_l.data_loglike(data)
+    assert abs(ll - O.nonstationary_fit(X, Y[0], lamL, np.full(N, 1.1), np.full(N, 0.05)).logpdf) <= 1e-9 * (1 + abs(ll))
+    post.close()
+    for p in posts:
+        p.close()
