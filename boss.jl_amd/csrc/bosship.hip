@@ -1237,12 +1237,13 @@ __global__ void scale_cand_kernel(const double* __restrict__ Craw, double* __res
     }
 }
 
-// candidate tiles (of 32) up to which the resident-inverse GEMMs beat the step-by-step substitution (measured at N=4096:
-// 0.19 vs 0.59 ms at 7 tiles, 0.61 vs 0.85 ms at 32, equal at 64, slower beyond)
+// candidate tiles (of 32) up to which the resident-inverse GEMMs replace the step-by-step substitution (measured at N=4096:
+// 0.19 vs 0.59 ms at 7 tiles, 0.46 vs 0.85 ms at 32, 0.75 vs 1.16 ms at 64, 1.36 vs 1.85 ms at 128 = the whole few-candidates range)
 static int invgemm_max_tiles() {
-    static const int v = getenv("BOSS_INVGEMM_MAX_TILES") ? atoi(getenv("BOSS_INVGEMM_MAX_TILES")) : 48;
+    static const int v = getenv("BOSS_INVGEMM_MAX_TILES") ? atoi(getenv("BOSS_INVGEMM_MAX_TILES")) : 128;
     return v;
 }
+
 
 // U = L⁻ᵀ (upper, leading dimension g->ld) by recursive doubling from the 256×256 diagonal inverses; Lw (same shape)
 // is the lower work matrix.  Dinv2 must be current on stream s.
@@ -1343,7 +1344,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
             rc = ws_reserve(c->lgC, sizeof(double) * (size_t)ftiles * nrb * 64);
             if (rc) return rc;
             double* ssp = (double*)c->lgC.p;
-            hipLaunchKernelGGL(inv_fwd_kernel<GU>, dim3(nrb, ftiles), dim3(GU::NTHREADS), 0, s, (const double*)g->Linv, g->ld, g->Np,
+            hipLaunchKernelGGL(inv_fwd_kernel<GU>, dim3(ftiles, nrb), dim3(GU::NTHREADS), 0, s, (const double*)g->Linv, g->ld, g->Np,
                                (const double*)g->A, g->ld, (const double*)R, V, ssp);
             hipLaunchKernelGGL(inv_fwd_finish_kernel, dim3(ftiles), dim3(256), 0, s, (const double*)ssp, nrb, mean_s_dev, cd->M,
                                g->amp2, g->aug ? 1 : g->gibbs ? 2 : 0, mu, var);
@@ -1370,7 +1371,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
                                mean_s_dev, cd->M, g->amp2, mu, var, g->aug ? 1 : g->gibbs ? 2 : 0);
             const int nupd = (nb - 1 - ib) * (PRED_RB / BLK);
             if (nupd > 0)
-                hipLaunchKernelGGL(few_update_kernel<GU>, dim3(nupd, ftiles), dim3(GU::NTHREADS), 0, s, (const double*)g->A, g->ld,
+                hipLaunchKernelGGL(few_update_kernel<GU>, dim3(ftiles, nupd), dim3(GU::NTHREADS), 0, s, (const double*)g->A, g->ld,
                                    g->Np, ib, (const double*)V, R);
         }
         if (g->gibbs) hipLaunchKernelGGL(gibbs_var_kernel, dim3((cd->M + 255) / 256), dim3(256), 0, s, var, camp_dev, cd->M);
@@ -1603,7 +1604,7 @@ static int grad_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_de
         // both inverse factors are resident (repeated calls on this factorisation): W = L⁻ᵀV as one GEMM
         typedef GemmDirect<4, 1, 2, 2, 8> GU;
         double* Wsl = slabs + (size_t)tiles * 32 * Np;
-        hipLaunchKernelGGL(inv_bwd_kernel<GU>, dim3(Np / BLK, tiles), dim3(GU::NTHREADS), 0, s, (const double*)g->Winv, g->ld, Np,
+        hipLaunchKernelGGL(inv_bwd_kernel<GU>, dim3(tiles, Np / BLK), dim3(GU::NTHREADS), 0, s, (const double*)g->Winv, g->ld, Np,
                            (const double*)slabs, Wsl);
         slabs = Wsl;
     } else if (tiles <= few_max_tiles && Np >= 4 * PRED_RB && !no_few) {
@@ -1613,7 +1614,7 @@ static int grad_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s_de
             hipLaunchKernelGGL(few_back_finish_kernel<G>, dim3(tiles), dim3(G::NTHREADS), PredictLds<G>::BYTES, s,
                                (const double*)g->DT2, Np, ib, slabs);
             if (ib > 0)
-                hipLaunchKernelGGL(few_back_update_kernel<GU>, dim3(ib * (PRED_RB / BLK), tiles), dim3(GU::NTHREADS), 0, s,
+                hipLaunchKernelGGL(few_back_update_kernel<GU>, dim3(tiles, ib * (PRED_RB / BLK)), dim3(GU::NTHREADS), 0, s,
                                    (const double*)g->LT, g->ld, Np, ib, slabs);
         }
     } else {

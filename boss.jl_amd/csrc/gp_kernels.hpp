@@ -511,11 +511,12 @@ __global__ __launch_bounds__(GU::NTHREADS) void few_update_kernel(const double* 
                                                                   const double* __restrict__ V, double* __restrict__ R) {
     static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
     constexpr int TM = GU::TM, TN = GU::TN;
-    V += (size_t)blockIdx.y * Np * 32;                       // candidate tile
-    R += (size_t)blockIdx.y * Np * 32;
+    V += (size_t)blockIdx.x * Np * 32;                       // candidate tile (fastest in dispatch order: the tiles of one
+                                                             // row block share its panel of L in L2)
+    R += (size_t)blockIdx.x * Np * 32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r0 = (ib + 1) * PRED_RB + blockIdx.x * BLK;    // first row of this workgroup's block
+    const int r0 = (ib + 1) * PRED_RB + blockIdx.y * BLK;    // first row of this workgroup's block
     double* Rb = R + (size_t)r0 * 32;
     v4d acc[TM][TN];
 #pragma unroll
@@ -699,27 +700,30 @@ __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict
 // factors resident the substitutions are plain GEMMs without any sequential step,
 //   inv_fwd_kernel   V = L⁻¹ K*   (A operand = the lower inverse, k range up to the row block),  Σv², v·z partials per row block
 //   inv_bwd_kernel   W = L⁻ᵀ V    (A operand = the upper inverse, k range from the row block)    — the adjoint pass of the gradients
-// on 128×32 tiles, one workgroup per (row block, candidate tile).
+// on 128×32 tiles, one workgroup per (row block, candidate tile); the candidate tiles of one row block are neighbours in
+// dispatch order, so they share that row block's panel of the inverse in L2 (row-block-fastest order streamed every panel
+// from HBM once per tile: 37 TF instead of 50; 256×32 tiles were no faster).
 template <class GU>
 __global__ __launch_bounds__(GU::NTHREADS) void inv_fwd_kernel(const double* __restrict__ Linv, int ldl, int Np,
                                                                const double* __restrict__ Afac, int ld,
                                                                const double* __restrict__ Kst, double* __restrict__ Vslabs,
                                                                double* __restrict__ ssp) {
-    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32 && GU::WR == 4, "128×32 tiles, four waves stacked along the rows");
-    constexpr int TM = GU::TM, TN = GU::TN;
+    static_assert(GU::WC == 1 && GU::BN == 32 && GU::WR == 4, "(128 or 256)×32 tiles, four waves stacked along the rows");
+    constexpr int TM = GU::TM, TN = GU::TN, BM = GU::BM;
     __shared__ double red[2][4][32];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rb = gridDim.x - 1 - blockIdx.x;               // deepest row blocks first
-    const int r0 = rb * BLK;
-    const double* B = Kst + (size_t)blockIdx.y * Np * 32;
-    double* V = Vslabs + (size_t)blockIdx.y * Np * 32;
+    const int rb = gridDim.y - 1 - blockIdx.y;               // deepest row blocks first; candidate tiles of one row block are
+                                                             // neighbours in dispatch order and share its panel of the inverse in L2
+    const int r0 = rb * BM;
+    const double* B = Kst + (size_t)blockIdx.x * Np * 32;
+    double* V = Vslabs + (size_t)blockIdx.x * Np * 32;
     v4d acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-    GU::template run<1>(Linv + r0, ldl, B, 32, r0 + BLK, acc);
+    GU::template run<1>(Linv + r0, ldl, B, 32, r0 + BM, acc);
     double ps[TN][4], pz[TN][4];
 #pragma unroll
     for (int n = 0; n < TN; ++n)
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(GU::NTHREADS) void inv_fwd_kernel(const double* __r
     __syncthreads();
     if (threadIdx.x < 64) {
         const int q = threadIdx.x >> 5, col = threadIdx.x & 31;
-        ssp[((size_t)blockIdx.y * gridDim.x + rb) * 64 + threadIdx.x] = red[q][0][col] + red[q][1][col] + red[q][2][col] + red[q][3][col];
+        ssp[((size_t)blockIdx.x * gridDim.y + rb) * 64 + threadIdx.x] = red[q][0][col] + red[q][1][col] + red[q][2][col] + red[q][3][col];
     }
 }
 
@@ -787,13 +791,13 @@ __global__ __launch_bounds__(256) void inv_fwd_finish_kernel(const double* __res
 template <class GU>
 __global__ __launch_bounds__(GU::NTHREADS) void inv_bwd_kernel(const double* __restrict__ Uinv, int ldu, int Np,
                                                                const double* __restrict__ Vslabs, double* __restrict__ Wslabs) {
-    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
+    static_assert(GU::WC == 1 && GU::BN == 32, "(128 or 256)×32 tiles");
     constexpr int TM = GU::TM, TN = GU::TN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r0 = blockIdx.x * BLK;                         // block 0 is the deepest here
-    const double* V = Vslabs + (size_t)blockIdx.y * Np * 32;
-    double* W = Wslabs + (size_t)blockIdx.y * Np * 32;
+    const int r0 = blockIdx.y * GU::BM;                      // block 0 is the deepest here; tiles of one row block are neighbours
+    const double* V = Vslabs + (size_t)blockIdx.x * Np * 32;
+    double* W = Wslabs + (size_t)blockIdx.x * Np * 32;
     v4d acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -1042,8 +1046,8 @@ __global__ __launch_bounds__(GU::NTHREADS) void few_back_update_kernel(const dou
     constexpr int TM = GU::TM, TN = GU::TN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* V = Vslabs + (size_t)blockIdx.y * Np * 32;
-    const int r0 = blockIdx.x * BLK;                         // rows before step ib
+    double* V = Vslabs + (size_t)blockIdx.x * Np * 32;
+    const int r0 = blockIdx.y * BLK;                         // rows before step ib
     double* Rb = V + (size_t)r0 * 32;
     v4d acc[TM][TN];
 #pragma unroll
