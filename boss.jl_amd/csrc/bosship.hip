@@ -212,6 +212,7 @@ struct boss_gp {
     double *Winv = nullptr, *Linv = nullptr;   // L⁻ᵀ (upper) and L⁻¹ (lower)
     bool have_winv = false;
     int few_calls = 0;
+    int append_calls = 0;                      // single-observation appends since the last update (the second one builds the inverses)
 };
 
 struct boss_cand {
@@ -230,6 +231,7 @@ struct boss_track {                            // resident predictive state of (
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static void linv_enqueue(boss_gp* g, hipStream_t s, double* U, double* Lw);
 // largest system the entry points accept: element offsets into the factor stay below 2^31 (exercised up to
 // 36 864 rows = 10.9 GB by the tests)
 constexpr int MAX_ROWS = 46080;
@@ -718,6 +720,7 @@ extern "C" int boss_gp_update(boss_gp_t* g, const double* lengthscale, double am
     g->few_calls = 0;
     g->have_lt = false;
     ++g->epoch;
+    g->append_calls = 0;
     // +1e-8 on every parameter (gaussian_process.jl:239-241)
     HIPCHK(hipEventSynchronize(g->par_ev));   // previous update's staging copies have been consumed
     double* invlam = g->host_par;
@@ -764,6 +767,7 @@ extern "C" int boss_ggp_update(boss_gp_t* g, const double* lengthscale, double a
     g->have_winv = false;
     g->few_calls = 0;
     ++g->epoch;
+    g->append_calls = 0;
     HIPCHK(hipEventSynchronize(g->par_ev));
     double* invlam = g->host_par;
     double* hyp = g->host_par + g->d;
@@ -812,6 +816,7 @@ extern "C" int boss_ngp_update(boss_gp_t* g, const double* lam_X, const double* 
     g->have_winv = false;
     g->few_calls = 0;
     ++g->epoch;
+    g->append_calls = 0;
     HIPCHK(hipMemcpyAsync(g->lamX, lam.data(), sizeof(double) * d * Np, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->ampX, amp.data(), sizeof(double) * Np, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->noiseX, noi.data(), sizeof(double) * Np, hipMemcpyHostToDevice, s));
@@ -915,6 +920,7 @@ extern "C" int boss_gp_reserve(boss_gp_t* g, int N_total) {
     if (rc) return rc;
     g->fitted = false;
     ++g->epoch;
+    g->append_calls = 0;
     return BOSS_OK;
 }
 
@@ -933,13 +939,39 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
     hipStream_t s = c->stream;
     const int d = g->d, N0 = g->N, N1 = N0 + n;
     const int Np_before = g->Np;
+    // one observation into existing storage, not the first such append on these hyper-parameters: rank-one append on the
+    // resident inverse factors (built here if they are not resident yet)
+    static const int winv_after = getenv("BOSS_WINV_AFTER") ? atoi(getenv("BOSS_WINV_AFTER")) : 2;
+    bool fast = false;
+    if (n == 1 && N1 <= g->Np && winv_after > 0 && sizeof(double) * (size_t)g->Np <= 144 * 1024) {
+        if (!g->have_winv && ++g->append_calls >= 2 && g->few_calls >= 0) {
+            const size_t bytes = sizeof(double) * (size_t)g->ld * g->Np;
+            bool ok = (g->Winv != nullptr || dev_malloc((void**)&g->Winv, bytes) == hipSuccess) &&
+                      (g->Linv != nullptr || dev_malloc((void**)&g->Linv, bytes) == hipSuccess);
+            if (ok) {
+                dinv_join(g);
+                if (!g->have_dinv) {
+                    dinv_launch(g, s);
+                    g->have_dinv = true;
+                }
+                linv_enqueue(g, s, g->Winv, g->Linv);
+                g->have_winv = true;
+            } else {
+                (void)hipGetLastError();
+                g->few_calls = -(1 << 30);
+            }
+        }
+        fast = g->have_winv;
+    }
     int rc = gp_grow(g, N1);
     if (rc) return rc;
     g->fitted = false;
-    g->have_dinv = false;
-    g->have_winv = false;
-    g->few_calls = 0;
     g->have_lt = false;
+    if (!fast) {
+        g->have_dinv = false;
+        g->have_winv = false;
+        g->few_calls = 0;
+    }
     {
         std::vector<double> xb;
         pack_points(xb, X_new, d, n, n, g->discrete.empty() ? nullptr : g->discrete.data());
@@ -953,6 +985,48 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
         HIPCHK(hipStreamSynchronize(s));       // staging buffers go out of scope
     }
     g->N = N1;
+    if (fast) {
+        const int Np = g->Np, ld = g->ld, nwg = Np / WINV_ROWS;
+        dinv_join(g);
+        if (!g->have_dinv) {                                 // the patched blocks must exist
+            dinv_launch(g, s);
+            g->have_dinv = true;
+        }
+        rc = ws_reserve(c->few, sizeof(double) * ((size_t)Np * 32 + (size_t)nwg * 8 + 2 * (size_t)Np + 8));
+        if (rc) return rc;
+        rc = ws_reserve(c->csc, sizeof(double) * (size_t)d * 64);
+        if (rc) return rc;
+        double* R = (double*)c->few.p;                       // k = K(X, x_new) in column 0 of a 32-wide tile
+        double* part = R + (size_t)Np * 32;
+        double* lvec = part + (size_t)nwg * 8;
+        double* wvec = lvec + Np;
+        double* dz = wvec + Np;
+        double* Csc = (double*)c->csc.p;
+        HIPCHK(hipMemsetAsync(g->info, 0, sizeof(int), s));
+        hipLaunchKernelGGL(scale_points_kernel, dim3((Np + 255) / 256, 1, 1), dim3(256), 0, s, g->Xraw, g->Xsc, (size_t)0, g->invlam, d, Np);
+        // the new (scaled) point as candidate 0 of a 64-wide candidate block
+        HIPCHK(hipMemcpy2DAsync(Csc, sizeof(double) * 64, g->Xsc + N0, sizeof(double) * Np, sizeof(double), d, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(kstar_rows_kernel, dim3(Np / 256, 1), dim3(256), sizeof(double) * d * 32, s, (const double*)g->Xsc, Np, N0,
+                           (const double*)Csc, d, 64, g->kernel, g->amp2, R, 1);
+        hipLaunchKernelGGL(winv_gemv_kernel<1>, dim3(nwg), dim3(256), sizeof(double) * (size_t)Np, s, (const double*)g->Winv, ld, Np,
+                           (const double*)g->A, ld, (const double*)R, 1, part, lvec);
+        hipLaunchKernelGGL(append_scalars_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nwg, (const double*)g->hyp,
+                           (const double*)g->y, (const double*)g->mean, N0, g->scal, dz, g->info);
+        hipLaunchKernelGGL(linv_col_gemv_kernel, dim3((N0 + 7) / 8), dim3(256), 0, s, (const double*)g->Linv, ld, N0,
+                           (const double*)lvec, wvec);
+        hipLaunchKernelGGL(append_write_kernel, dim3(N0 / 256 + 1), dim3(256), 0, s, g->A, ld, Np, N0, (const double*)lvec,
+                           (const double*)wvec, (const double*)dz, g->Linv, g->Winv, g->Dinv, g->Dinv2, g->inv16);
+        HIPCHK(hipMemcpyAsync(g->host_res, g->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&g->host_res[2], g->info, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipGetLastError());
+        g->pending = true;
+        rc = gp_finish(g, logpdf_out);
+        if (rc) {                                            // not positive definite: nothing resident describes the data any more
+            g->have_dinv = false;
+            g->have_winv = false;
+        }
+        return rc;
+    }
     // block rows to (re)build: those holding new observations and, when the storage has just grown, the pure padding
     // block rows behind them as well (identity blocks of the factor and their inverses: the new arrays are uninitialised)
     const int kb0 = N0 / BLK, kb1 = (g->Np != Np_before) ? g->nblk - 1 : (N1 - 1) / BLK;
@@ -1358,7 +1432,7 @@ static int predict_enqueue(boss_gp* g, const boss_cand* cd, const double* mean_s
             const size_t lds = sizeof(double) * (size_t)g->Np * mc;
             auto kfn = mc == 1 ? winv_gemv_kernel<1> : mc == 2 ? winv_gemv_kernel<2> : winv_gemv_kernel<4>;
             hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), lds, s, (const double*)g->Winv, g->ld, g->Np,
-                               (const double*)g->A, g->ld, (const double*)R, cd->M, part);
+                               (const double*)g->A, g->ld, (const double*)R, cd->M, part, (double*)nullptr);
             hipLaunchKernelGGL(winv_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nwg, cd->M, mean_s_dev, g->amp2,
                                g->aug ? 1 : g->gibbs ? 2 : 0, mu, var);
             if (g->gibbs) hipLaunchKernelGGL(gibbs_var_kernel, dim3(1), dim3(256), 0, s, var, camp_dev, cd->M);

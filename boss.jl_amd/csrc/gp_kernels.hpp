@@ -634,7 +634,9 @@ constexpr int WINV_MAX_M = 4;
 template <int MC>                                            // candidates staged per call: 1, 2 or 4
 __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict__ U, int ldu, int Np,
                                                         const double* __restrict__ Afac, int ld,
-                                                        const double* __restrict__ R, int M, double* __restrict__ part) {
+                                                        const double* __restrict__ R, int M, double* __restrict__ part,
+                                                        double* __restrict__ vout) {
+    // vout (or null): v itself for candidate 0 — the new factor row of a rank-one append
     extern __shared__ double ks[];                           // K* [c][MC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int idx = tid; idx < Np * MC; idx += 256) {
@@ -682,6 +684,10 @@ __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict
         }
         ss[j] = __builtin_fma(v0, v0, v1 * v1);
         mz[j] = __builtin_fma(v0, z0, v1 * z1);
+        if (j == 0 && vout && lane == 0) {
+            vout[k0] = v0;
+            vout[k0 + 1] = v1;
+        }
     }
     __syncthreads();                                         // ks no longer needed: its head takes the wave partials
     if (lane == 0) {
@@ -812,6 +818,93 @@ __global__ __launch_bounds__(GU::NTHREADS) void inv_bwd_kernel(const double* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) W[(size_t)row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Rank-one append on resident inverse factors (boss_gp_append with one observation, from the second append on a set
+// of hyper-parameters): with l = L⁻¹k (winv_gemv_kernel, vout), d = sqrt(k(x,x) + σ² − lᵀl), z_new = (y − m − lᵀz)/d
+//     L ← [L 0; lᵀ d] ,   L⁻¹ ← [L⁻¹ 0; −wᵀ/d  1/d] ,  w = L⁻ᵀ l
+// i.e. one pass over each inverse factor (2 × 67 MB at N = 4096) instead of sweeping the new block row through all
+// earlier panels.  The diagonal-block inverses the other kernels use (16×16, 128×128, 256×256) are the diagonal blocks
+// of L⁻¹, so the same row is patched into them.
+// ------------------------------------------------------------------------------------------
+// w_c = Σ_{r≥c} Linv[r, c] l_r  for c < N0: column c of the lower inverse is contiguous; one wave per two columns.
+__global__ __launch_bounds__(256) void linv_col_gemv_kernel(const double* __restrict__ Linv, int ldl, int N0,
+                                                            const double* __restrict__ l, double* __restrict__ w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 4 + wave) * 2;
+    if (c0 >= N0) return;
+    const double* col0 = Linv + (size_t)c0 * ldl;
+    const double* col1 = col0 + ldl;
+    const bool two = c0 + 1 < N0;
+    double a0 = 0.0, a1 = 0.0;
+    for (int r = c0 + lane; r < N0; r += 64) {
+        const double lr = l[r];
+        a0 = __builtin_fma(col0[r], lr, a0);
+        if (two && r > c0) a1 = __builtin_fma(col1[r], lr, a1);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a0 += __shfl_xor(a0, off);
+        a1 += __shfl_xor(a1, off);
+    }
+    if (lane == 0) {
+        w[c0] = a0;
+        if (two) w[c0 + 1] = a1;
+    }
+}
+
+// Σ of the gemv partials (fixed-order tree), then d, z_new; scal = {logdet, zᵀz} is advanced, dz = {d, z_new};
+// a non-positive d² is reported like a failed pivot (info = N0 + 1).
+__global__ __launch_bounds__(256) void append_scalars_kernel(const double* __restrict__ part, int nwg, const double* __restrict__ hyp,
+                                                             const double* __restrict__ y, const double* __restrict__ mean, int N0,
+                                                             double* __restrict__ scal, double* __restrict__ dz, int* __restrict__ info) {
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    double s = 0.0, z = 0.0;
+    for (int w = tid; w < nwg; w += 256) {
+        s += part[(size_t)w * 8];
+        z += part[(size_t)w * 8 + 1];
+    }
+    red[0][tid] = s;
+    red[1][tid] = z;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            red[0][tid] += red[0][tid + off];
+            red[1][tid] += red[1][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double d2 = hyp[0] + hyp[1] - red[0][0];
+        if (!(d2 > 0.0)) *info = N0 + 1;
+        const double dd = sqrt(d2), zn = (y[N0] - mean[N0] - red[1][0]) / dd;
+        dz[0] = dd;
+        dz[1] = zn;
+        scal[0] += 2.0 * log(dd);
+        scal[1] = __builtin_fma(zn, zn, scal[1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void append_write_kernel(double* __restrict__ A, int ld, int Np, int N0,
+                                                           const double* __restrict__ l, const double* __restrict__ w,
+                                                           const double* __restrict__ dz, double* __restrict__ Linv,
+                                                           double* __restrict__ U, double* __restrict__ Dinv,
+                                                           double* __restrict__ Dinv2, double* __restrict__ inv16) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c > N0) return;
+    const double dd = dz[0];
+    const bool diag = c == N0;
+    const double t = diag ? 1.0 / dd : -w[c] / dd;           // row N0 of L⁻¹
+    A[(size_t)c * ld + N0] = diag ? dd : l[c];               // row N0 of L
+    if (diag) A[(size_t)N0 * ld + Np] = dz[1];               // z_new (the δᵀ/z row block)
+    Linv[(size_t)c * ld + N0] = t;
+    U[(size_t)N0 * ld + c] = t;
+    const int b1 = N0 / BLK, b2 = N0 / PRED_RB, b16 = N0 / 16;
+    if (c >= b1 * BLK) Dinv[(size_t)b1 * BLK * BLK + (size_t)(c - b1 * BLK) * BLK + (N0 - b1 * BLK)] = t;
+    if (c >= b2 * PRED_RB) Dinv2[(size_t)b2 * PRED_RB * PRED_RB + (size_t)(c - b2 * PRED_RB) * PRED_RB + (N0 - b2 * PRED_RB)] = t;
+    if (c >= b16 * 16) inv16[(size_t)b1 * 8 * 256 + (size_t)(b16 - b1 * 8) * 256 + (c - b16 * 16) * 16 + (N0 - b16 * 16)] = t;
 }
 
 // mode: 0 plain (σ² = α² − Σv² + 1e-18), 1 gradient observations (max(0, α² − Σv²)), 2 nonstationary (−Σv²; gibbs_var_kernel follows)

@@ -205,6 +205,22 @@ def llgrad_timing(d=8, N=4096):
           f"rel err at N=512: {np.abs(g512-grad_o).max()/(1+np.abs(grad_o).max()):.1e}", flush=True)
 
 
+def append_fast_timing(d=8, N=4000, count=40):
+    """Single-observation appends: block path (first), inverse build (second), rank-one path (from then on)."""
+    X, y, _ = problem(d, N + count, 1)
+    g = api.GP(X[:, :N], y[:N], "matern52")
+    g.reserve(N + count)
+    g.update(np.full(d, 0.5), 1.0, 0.05)
+    ts = []
+    for i in range(count):
+        t = time.time()
+        g.append(X[:, N + i], y[N + i])
+        ts.append(time.time() - t)
+    print(f"append N={N}: first {ts[0]*1e3:.3f} ms, second (builds the inverses) {ts[1]*1e3:.3f} ms, "
+          f"then {np.median(ts[2:])*1e3:.3f} ms median ({min(ts[2:])*1e3:.3f} min)", flush=True)
+    g.close()
+
+
 def few_timing(d=8, N=4096):
     """The reference's call pattern: one candidate per call."""
     X, y, Xs = problem(d, N, 64)
@@ -394,6 +410,8 @@ if __name__ == "__main__":
         ggp_parity(8, 150, 40, "sqexp", dup=True)
     if "ggp_big" in stages:
         ggp_timing(n=int(os.environ.get("GGP_N", "1024")))
+    if "append_fast" in stages:
+        append_fast_timing()
     if "ngp" in stages:
         ngp_timing()
     if "parity_big" in stages:

@@ -357,12 +357,17 @@ def test_full_size_next_rows(api, O):
     g.update(lam, 1.0, 0.05)
     tr.close()
     tr = api.Track(g, cand)
-    # (2) five appended observations: bit-identical to a fresh factorisation; the tracked moments follow
-    for i in range(5):
+    # (2) five appended observations: the first (block path) is bit-identical to a fresh factorisation of the same data,
+    #     the others (rank-one path on the resident inverses) agree to rounding; the tracked moments follow
+    lpa = g.append(X[:, N], y[N])
+    g1 = api.GP(X[:, :N + 1], y[:N + 1], "matern52")
+    assert lpa == g1.update(lam, 1.0, 0.05)
+    g1.close()
+    for i in range(1, 5):
         lpa = g.append(X[:, N + i], y[N + i])
     g2 = api.GP(X, y, "matern52")
     lp2 = g2.update(lam, 1.0, 0.05)
-    assert lpa == lp2
+    assert abs(lpa - lp2) <= 1e-11 * (1 + abs(lp2))
     mu_t, var_t = tr.moments()
     mu_f, var_f = g2.predict(Xs)
     assert np.allclose(mu_t, mu_f, rtol=0, atol=1e-10) and np.allclose(np.maximum(var_t, 0), var_f, rtol=0, atol=1e-10)
@@ -1433,3 +1438,64 @@ def test_nonstationary_gp_with_parametrized_gp_latents(api, O):
     post.close()
     for p in posts:
         p.close()
+
+
+@pytest.mark.parametrize("N0,count", [(1000, 6), (1279, 3), (2040, 12), (4090, 5)])
+def test_rank_one_appends_on_resident_inverses(api, O, N0, count):
+    """Single-observation appends: from the second one on a set of hyper-parameters the factor, z, the log-likelihood and
+    every inverse the prediction paths use are extended by one row from the resident inverse factors.  Every state in
+    between equals a fresh fit of the augmented data: factor, logpdf, small and large predictions, gradients, tracked
+    candidates; storage growth and a new update switch back cleanly."""
+    rng = np.random.default_rng(N0)
+    d = 3
+    X = rng.uniform(0, 1, (d, N0 + count))
+    y = np.sin(3 * X).sum(0) / 2 + 0.05 * rng.standard_normal(N0 + count)
+    mean = 0.1 * X[0]
+    lam = np.array([0.4, 0.5, 0.6])
+    Xs = np.asfortranarray(rng.uniform(0, 1, (d, 300)))
+    g = api.GP(X[:, :N0], y[:N0], "matern52")
+    g.reserve(N0 + count)
+    g.update(lam, 1.1, 0.05, mean[:N0])
+    cand = api.Candidates(Xs[:, :100])
+    tr = api.Track(g, cand, 0.1 * Xs[0, :100])
+    for i in range(count):
+        n1 = N0 + i + 1
+        lp = g.append(X[:, n1 - 1], y[n1 - 1], mean[n1 - 1:n1])
+        post = O.gp_fit(X[:, :n1], y[:n1], "matern52", lam, 1.1, 0.05, mean=mean[:n1])
+        assert abs(lp - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf)), i
+        L, z = g.factor()
+        assert np.abs(L - post.L).max() <= 1e-10 and np.abs(z - np.linalg.solve(post.L, y[:n1] - mean[:n1])).max() <= 1e-9, i
+        for M in (1, 40, 300):                               # one-pass kernel, inverse GEMMs, (first call) step path
+            mu, var = g.predict(Xs[:, :M], 0.1 * Xs[0, :M])
+            mu_o, var_o = O.gp_mean_and_var(post, Xs[:, :M], 0.1 * Xs[0, :M])
+            assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), (i, M)
+        mu_t, var_t = tr.moments()
+        mu_o, var_o = O.gp_mean_and_var(post, Xs[:, :100], 0.1 * Xs[0, :100], clip=False)
+        assert np.allclose(mu_t, mu_o, rtol=0, atol=1e-9) and np.allclose(var_t, var_o, rtol=0, atol=1e-9), i
+    mu, var, dmu, dvar = g.predict_grad(Xs[:, :20], 0.1 * Xs[0, :20])
+    _, _, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs[:, :20], 0.1 * Xs[0, :20])
+    assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8 * (1 + np.abs(dmu_o).max()))
+    assert np.allclose(dvar, dvar_o, rtol=0, atol=1e-8 * (1 + np.abs(dvar_o).max()))
+    _, gr = g.loglike_grad()
+    _, gr_o = O.gp_data_loglike_grad(X, y, "matern52", lam, 1.1, 0.05, mean=mean)
+    assert np.allclose(gr, gr_o, rtol=0, atol=1e-8 * (1 + np.abs(gr_o).max()))
+    # the full 8192-candidate kernel reads the patched 256×256 inverses
+    Xb = np.asfortranarray(rng.uniform(0, 1, (d, 4200)))
+    mu_b, var_b = g.predict(Xb)
+    mu_bo, var_bo = O.gp_mean_and_var(O.gp_fit(X, y, "matern52", lam, 1.1, 0.05, mean=mean), Xb[:, :200])
+    assert np.allclose(mu_b[:200], mu_bo, rtol=0, atol=1e-9) and np.allclose(var_b[:200], var_bo, rtol=0, atol=1e-9)
+    # one more append grows the storage (block path), then appends on the new storage, then a re-fit
+    xg = rng.uniform(0, 1, (d, 3))
+    Xa, ya, ma = X, y, mean
+    for j in range(3):
+        lp = g.append(xg[:, j], 0.2, [0.1 * xg[0, j]])
+        Xa, ya, ma = np.hstack([Xa, xg[:, j:j + 1]]), np.append(ya, 0.2), np.append(ma, 0.1 * xg[0, j])
+        post = O.gp_fit(Xa, ya, "matern52", lam, 1.1, 0.05, mean=ma)
+        assert abs(lp - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf)), j
+        mu, var = g.predict(Xs[:, :3], 0.1 * Xs[0, :3])
+        mu_o, var_o = O.gp_mean_and_var(post, Xs[:, :3], 0.1 * Xs[0, :3])
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), j
+    lp = g.update(lam * 1.2, 1.0, 0.06, ma)
+    assert abs(lp - O.gp_fit(Xa, ya, "matern52", lam * 1.2, 1.0, 0.06, mean=ma).logpdf) <= 1e-9 * (1 + abs(lp))
+    tr.close()
+    g.close()
