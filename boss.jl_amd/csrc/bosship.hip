@@ -924,6 +924,8 @@ extern "C" int boss_gp_reserve(boss_gp_t* g, int N_total) {
     return BOSS_OK;
 }
 
+static int append_locked(boss_gp* g, int n, const double* X_new, const double* y_new, const double* mean_new, double* logpdf_out);
+
 extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const double* y_new, const double* mean_new,
                               double* logpdf_out) {
     if (!g || n < 1 || !X_new || !y_new) return fail(BOSS_E_INVALID, "need a handle, n >= 1 and non-NULL X_new, y_new");
@@ -931,6 +933,19 @@ extern "C" int boss_gp_append(boss_gp_t* g, int n, const double* X_new, const do
     Ctx* c = g->ctx;
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);
+    if (n > 1 && n <= 8 && g->have_winv && g->fitted && !g->pending && g->N + n <= g->Np) {
+        // a handful of observations on resident inverse factors: n rank-one appends beat one block-row sweep
+        int rc = BOSS_OK;
+        for (int j = 0; j < n && rc == BOSS_OK; ++j)
+            rc = append_locked(g, 1, X_new + (size_t)j * g->d, y_new + j, mean_new ? mean_new + j : nullptr, logpdf_out);
+        return rc;
+    }
+    return append_locked(g, n, X_new, y_new, mean_new, logpdf_out);
+}
+
+// caller holds the context lock
+static int append_locked(boss_gp* g, int n, const double* X_new, const double* y_new, const double* mean_new, double* logpdf_out) {
+    Ctx* c = g->ctx;
     if (g->pending) {
         int rc0 = gp_finish(g, nullptr);
         if (rc0) return rc0;

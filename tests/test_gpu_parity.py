@@ -1472,6 +1472,17 @@ def test_rank_one_appends_on_resident_inverses(api, O, N0, count):
         mu_t, var_t = tr.moments()
         mu_o, var_o = O.gp_mean_and_var(post, Xs[:, :100], 0.1 * Xs[0, :100], clip=False)
         assert np.allclose(mu_t, mu_o, rtol=0, atol=1e-9) and np.allclose(var_t, var_o, rtol=0, atol=1e-9), i
+    if count >= 6:                                           # a few observations at once on the resident inverses
+        g3 = api.GP(X[:, :N0], y[:N0], "matern52")
+        g3.reserve(N0 + count)
+        g3.update(lam, 1.1, 0.05, mean[:N0])
+        g3.append(X[:, N0], y[N0], mean[N0:N0 + 1])
+        g3.append(X[:, N0 + 1], y[N0 + 1], mean[N0 + 1:N0 + 2])
+        lp3 = g3.append(X[:, N0 + 2:N0 + 6], y[N0 + 2:N0 + 6], mean[N0 + 2:N0 + 6])
+        p3 = O.gp_fit(X[:, :N0 + 6], y[:N0 + 6], "matern52", lam, 1.1, 0.05, mean=mean[:N0 + 6])
+        assert abs(lp3 - p3.logpdf) <= 1e-9 * (1 + abs(p3.logpdf))
+        assert np.abs(g3.factor()[0] - p3.L).max() <= 1e-10
+        g3.close()
     mu, var, dmu, dvar = g.predict_grad(Xs[:, :20], 0.1 * Xs[0, :20])
     _, _, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs[:, :20], 0.1 * Xs[0, :20])
     assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8 * (1 + np.abs(dmu_o).max()))
