@@ -1,0 +1,697 @@
+// predict_kernels.hpp — posterior prediction: the fused kernel (K* tile → blocked substitution → Σv², v·z), the
+// step-by-step path for few candidates, the resident-inverse paths (one-pass GEMV, inverse GEMMs, rank-one append)
+// and the diagonal-block inverses they share.
+#pragma once
+#include "gram_kernels.hpp"
+
+namespace boss {
+
+// ------------------------------------------------------------------------------------------
+// K4-K7 fused prediction.  One workgroup owns BN candidates and walks the row blocks of L:
+//     R_i = K*_i − Σ_{j<i} L_ij V_j          (MFMA GEMM, V_j re-read from its own scratch slab)
+//     V_i = Dinv_i · R_i                      (MFMA GEMM, R_i resident in LDS)
+//     ss += colsum(V_i²) ,  mz += V_i^T z_i
+// which is the blocked form of  V = C.U' \ K*  (AbstractGPs var(post(X*))), with
+// μ − m(X*) = K*^T a = V^T z  accumulated in the same pass.  K* never touches HBM.
+// ------------------------------------------------------------------------------------------
+template <class G>
+struct PredictLds {
+    static constexpr int LDR = G::BN + 16;
+    static constexpr int PART = 2 * G::TN * 4;       // per-thread Σv², v·z partials, parked in LDS between row blocks
+    static constexpr int BYTES = (G::BM * LDR + 2 * G::WR * G::BN + G::NTHREADS * PART) * 8;
+};
+
+// G = GemmDirect<WR,1,TM,TN,D> with RB = WR·TM·16 ∈ {128, 256}: WR waves stacked along the RB rows of a
+// substitution step, BN = 16·TN candidates; Dinv holds the dense inverses of the RB×RB diagonal blocks.
+// Both GEMMs stream their A operand (L row block / Dinv_i) straight from L2 through a register
+// ring; GEMM1's B operand is the workgroup's own V slab (global, candidate-contiguous), GEMM2's
+// B operand is the R tile in LDS.  Three barriers per row block, none inside the GEMMs.
+// PRE: the right-hand side K* is not evaluated here but was written to the workgroup's V slab beforehand
+// (gradient-observation posteriors, aug_kstar_kernel); block ib's rows are consumed before V_ib overwrites them.
+template <class G, bool PRE = false>
+__global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
+                                                      const double* __restrict__ Dinv,
+                                                      const double* __restrict__ Xsc,
+                                                      const double* __restrict__ Csc, int d, int Mp, int kern,
+                                                      double amp2, double* __restrict__ Vscratch,
+                                                      const double* __restrict__ mean_s, int M,
+                                                      double* __restrict__ mu_out, double* __restrict__ var_out, int dbg) {
+    static_assert(G::WC == 1 && (G::BM == BLK || G::BM == 2 * BLK), "waves stacked along a 128- or 256-row block");
+    constexpr int RB = G::BM;                          // rows per substitution step; Dinv holds RB×RB inverses
+    extern __shared__ double lds[];
+    constexpr int BN = G::BN, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
+    double* Rs = lds;
+    double* red = Rs + RB * LDR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar wave index (see gemm_f64.hpp)
+    const int wr = wave, wc = 0;
+    const int c0 = blockIdx.x * BN;
+    double* V = Vscratch + (size_t)blockIdx.x * Np * BN;
+    const int nblk = Np / RB;
+
+    // per-thread partial sums live in LDS between row blocks (slot-major [slot][tid]: conflict-free).
+    // In registers they push the 64-candidate instantiation over 256 VGPRs; hipcc then spills to AGPRs
+    // and copies the inline-asm prefetch ring's registers BEFORE their loads have landed.
+    double* part = red + 2 * G::WR * G::BN;
+#pragma unroll
+    for (int u = 0; u < 2 * TN * 4; ++u) part[u * G::NTHREADS + tid] = 0.0;
+
+    for (int ib = 0; ib < nblk; ++ib) {
+        v4d acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        if (!(dbg & 4)) G::template run<1>(A + (size_t)ib * RB, ld, V, BN, ib * RB, acc);
+
+        // K*_ib tile in the accumulator layout
+        double r2[TM][TN][4];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r2[m][n][i] = 0.0;
+        for (int kd = 0; kd < ((dbg & 1) || PRE ? 0 : d); ++kd) {
+            double xr[TM], xc[TN][4];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) xr[m] = Xsc[(size_t)kd * Np + ib * RB + G::row_of(wr, m, lane)];
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xc[n][i] = Csc[(size_t)kd * Mp + c0 + G::col_of(wc, n, i, lane)];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double diff = xr[m] - xc[n][i];
+                        r2[m][n][i] = __builtin_fma(diff, diff, r2[m][n][i]);
+                    }
+        }
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int row = G::row_of(wr, m, lane);
+            const bool live = (ib * RB + row) < N;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double ks;
+                    if constexpr (PRE) ks = V[(size_t)(ib * RB + row) * BN + G::col_of(wc, n, i, lane)];
+                    else ks = (live && !(dbg & 1)) ? amp2 * kappa_r2(kern, r2[m][n][i]) : 0.0;
+                    Rs[row * LDR + G::col_of(wc, n, i, lane)] = ks - acc[m][n][i];
+                }
+        }
+        __syncthreads();                                   // R tile complete
+        v4d acc2[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+        // Dinv_i is lower triangular: a row only needs the k up to its own index.  With 256-row steps the
+        // waves take the 32-row groups {w, 7-w} (equal work); otherwise contiguous slices, k < 32 (w + 1).
+        constexpr bool TRI = (RB == 256 && G::PM == 2 && G::WR == 4);
+        if (!(dbg & 2)) {
+            if constexpr (TRI) G::run_Blds_tri(Dinv + (size_t)ib * RB * RB, RB, Rs, LDR, acc2);
+            else G::run_Blds(Dinv + (size_t)ib * RB * RB, RB, Rs, LDR, (TM * 16) * (wr + 1), acc2);   // K multiple of 16
+        }
+
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            int rloc;
+            if constexpr (TRI) rloc = G::tri_row_of(wr, m, lane);
+            else rloc = G::row_of(wr, m, lane);
+            const int row = ib * RB + rloc;
+            const double zr = A[(size_t)row * ld + Np];
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double v = acc2[m][n][i];
+                    if (!(dbg & 8)) V[(size_t)row * BN + G::col_of(wc, n, i, lane)] = v;
+                    double* ps = part + (size_t)(2 * (n * 4 + i)) * G::NTHREADS + tid;
+                    ps[0] = __builtin_fma(v, v, ps[0]);
+                    ps[G::NTHREADS] = __builtin_fma(v, zr, ps[G::NTHREADS]);
+                }
+        }
+        __syncthreads();   // V_ib visible to the whole workgroup (it is the next block's B operand); Rs reusable
+    }
+    // reduce over the 16 row-lanes, then over the 4 waves stacked along rows
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double s = part[(size_t)(2 * (n * 4 + i)) * G::NTHREADS + tid], z = part[(size_t)(2 * (n * 4 + i) + 1) * G::NTHREADS + tid];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                s += __shfl_xor(s, off);
+                z += __shfl_xor(z, off);
+            }
+            if ((lane & 15) == 0) {
+                const int col = G::col_of(wc, n, i, lane);
+                red[wr * BN + col] = s;
+                red[G::WR * BN + wr * BN + col] = z;
+            }
+        }
+    __syncthreads();
+    if (tid < BN) {
+        double s = 0.0, z = 0.0;
+#pragma unroll
+        for (int w = 0; w < G::WR; ++w) {
+            s += red[w * BN + tid];
+            z += red[G::WR * BN + w * BN + tid];
+        }
+        // μ = m(x*) + V^T z ;  σ² = k(x*,x*) − Σ V² + 1e-18   (unclipped; clipping is the consumer's job)
+        const int j = c0 + tid;
+        if (j < M) {
+            mu_out[j] = (mean_s ? mean_s[j] : 0.0) + z;
+            if constexpr (PRE) var_out[j] = (kern == KERN_GIBBS) ? -s       // per-candidate prior variance: gibbs_var_kernel
+                                                                 : fmax(0.0, amp2 - s);   // gradient_gp.jl:346: no jitter, clamped at 0
+            else var_out[j] = amp2 - s + PREDICT_JITTER;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Few candidates (M <= 32: the reference's own call pattern is ONE candidate per call,
+// expected_improvement.jl:75,79).  The fused kernel above gives one workgroup per 32 candidates, i.e.
+// ONE busy CU and ≈2.1 ms of latency at N=4096.  Here the substitution runs right-looking in 256-row
+// steps spread over the chip, on a residual array R (Np × 32) that starts as K*:
+//   kstar_rows_kernel   R = K* (all rows × 32 candidates), one row per thread
+//   few_finish_kernel   V_i = Dinv2_i R_i, Σv², v·z (and μ, σ² at the last step)           — one workgroup
+//   few_update_kernel   R_j −= L[j, i] V_i for every later row block j                       — one workgroup per 128 rows
+// Two short launches per step instead of one long-running workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kstar_rows_kernel(const double* __restrict__ Xsc, int Np, int N,
+                                                         const double* __restrict__ Csc, int d, int Mp, int kern,
+                                                         double amp2, double* __restrict__ kst, int ncols) {
+    // ncols: columns of the 32-wide tile that are needed (the one-to-four-candidates path reads only the first ones)
+    extern __shared__ double cs[];                           // [d][32]
+    const int c0 = blockIdx.y * 32;                          // candidate tile
+    kst += (size_t)blockIdx.y * Np * 32;
+    for (int idx = threadIdx.x; idx < d * 32; idx += 256) cs[idx] = Csc[(size_t)(idx >> 5) * Mp + c0 + (idx & 31)];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double r2[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) r2[c] = 0.0;
+    for (int kd = 0; kd < d; ++kd) {
+        const double xr = Xsc[(size_t)kd * Np + row];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            if (c < ncols) {
+                const double df = xr - cs[kd * 32 + c];
+                r2[c] = __builtin_fma(df, df, r2[c]);
+            }
+        }
+    }
+    const bool live = row < N;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+        if (c < ncols) kst[(size_t)row * 32 + c] = live ? amp2 * kappa_r2(kern, r2[c]) : 0.0;
+}
+
+// GU = GemmDirect<4,1,2,2,D>: 128 rows × 32 candidates per workgroup, K = 256
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void few_update_kernel(const double* __restrict__ A, int ld, int Np, int ib,
+                                                                  const double* __restrict__ V, double* __restrict__ R) {
+    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
+    constexpr int TM = GU::TM, TN = GU::TN;
+    V += (size_t)blockIdx.x * Np * 32;                       // candidate tile (fastest in dispatch order: the tiles of one
+                                                             // row block share its panel of L in L2)
+    R += (size_t)blockIdx.x * Np * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = (ib + 1) * PRED_RB + blockIdx.y * BLK;    // first row of this workgroup's block
+    double* Rb = R + (size_t)r0 * 32;
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][n][i] = Rb[row * 32 + GU::col_of(0, n, i, lane)];
+    }
+    GU::template run<-1>(A + (size_t)r0 + (size_t)ib * PRED_RB * ld, ld, V + (size_t)ib * PRED_RB * 32, 32, PRED_RB, acc);
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Rb[row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* __restrict__ A, int ld, int Np, int ib,
+                                                                 const double* __restrict__ R,
+                                                                 const double* __restrict__ Dinv2, double* __restrict__ V,
+                                                                 double* __restrict__ ssmz, int last,
+                                                                 const double* __restrict__ mean_s, int M, double amp2,
+                                                                 double* __restrict__ mu_out, double* __restrict__ var_out,
+                                                                 int aug) {
+    constexpr int RB = G::BM, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR, BN = 32;
+    extern __shared__ double lds[];
+    double* Rs = lds;
+    double* red = Rs + RB * LDR;                             // [2][WR][BN]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.x * BN;                          // candidate tile
+    R += (size_t)blockIdx.x * Np * 32;
+    V += (size_t)blockIdx.x * Np * 32;
+    ssmz += (size_t)blockIdx.x * 64;
+    const double* Rb = R + (size_t)ib * RB * 32;
+#pragma unroll 8
+    for (int q = 0; q < RB * 32 / 256; ++q) {                // coalesced copy of the step's residual rows into LDS
+        const int e = tid + 256 * q;
+        Rs[(e >> 5) * LDR + (e & 31)] = Rb[e];
+    }
+    __syncthreads();
+    v4d acc2[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    G::run_Blds_tri(Dinv2 + (size_t)ib * RB * RB, RB, Rs, LDR, acc2);
+    double ps[TN][4], pz[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ps[n][i] = pz[n][i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = ib * RB + G::tri_row_of(wave, m, lane);
+        const double zr = A[(size_t)row * ld + Np];
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double v = acc2[m][n][i];
+                V[(size_t)row * BN + G::col_of(0, n, i, lane)] = v;
+                ps[n][i] = __builtin_fma(v, v, ps[n][i]);
+                pz[n][i] = __builtin_fma(v, zr, pz[n][i]);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double s = ps[n][i], z = pz[n][i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                s += __shfl_xor(s, off);
+                z += __shfl_xor(z, off);
+            }
+            if ((lane & 15) == 0) {
+                const int col = G::col_of(0, n, i, lane);
+                red[wave * BN + col] = s;
+                red[G::WR * BN + wave * BN + col] = z;
+            }
+        }
+    __syncthreads();
+    if (tid < BN) {
+        double s = ssmz[tid], z = ssmz[BN + tid];
+#pragma unroll
+        for (int w = 0; w < G::WR; ++w) {
+            s += red[w * BN + tid];
+            z += red[G::WR * BN + w * BN + tid];
+        }
+        ssmz[tid] = s;
+        ssmz[BN + tid] = z;
+        if (last && c0 + tid < M) {
+            mu_out[c0 + tid] = (mean_s ? mean_s[c0 + tid] : 0.0) + z;
+            var_out[c0 + tid] = aug == 2 ? -s : aug ? fmax(0.0, amp2 - s) : amp2 - s + PREDICT_JITTER;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One to four candidates per call, many calls per posterior — the reference's own pattern
+// (`acq.(eachcol(xs))`, expected_improvement.jl:75,79).  From the second such call on a factorisation the
+// handle keeps U = L⁻ᵀ (recursive doubling, linv_level_kernel: ≈0.9 ms once) and a call is one pass over
+// its upper triangle:  v_k = Σ_{c≤k} U[c,k] k*_c  — column k of U is contiguous, one wave per row k with the
+// lanes along c, K* (≤ 4 columns) staged in LDS once per workgroup — 67 MB of coalesced reads at N=4096
+// instead of 16 dependent substitution steps.  Per-workgroup partials of Σv², v·z are summed in a fixed order.
+// ------------------------------------------------------------------------------------------
+constexpr int WINV_ROWS = 8;                                  // rows k per workgroup (two per wave)
+constexpr int WINV_MAX_M = 4;
+template <int MC>                                            // candidates staged per call: 1, 2 or 4
+__global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict__ U, int ldu, int Np,
+                                                        const double* __restrict__ Afac, int ld,
+                                                        const double* __restrict__ R, int M, double* __restrict__ part,
+                                                        double* __restrict__ vout) {
+    // vout (or null): v itself for candidate 0 — the new factor row of a rank-one append
+    extern __shared__ double ks[];                           // K* [c][MC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < Np * MC; idx += 256) {
+        const int c = idx / MC, j = idx % MC;
+        ks[idx] = (j < M) ? R[(size_t)c * 32 + j] : 0.0;
+    }
+    __syncthreads();
+    const int kb = (gridDim.x - 1 - blockIdx.x) * WINV_ROWS;  // longest rows first
+    const int k0 = kb + 2 * wave;                            // this wave's two rows, walked together (K* read once for both)
+    const double* col0 = U + (size_t)k0 * ldu;
+    const double* col1 = col0 + ldu;
+    double a0[MC], a1[MC];
+#pragma unroll
+    for (int j = 0; j < MC; ++j) a0[j] = a1[j] = 0.0;
+    int c = lane;
+    for (; c + 64 <= k0; c += 128) {                         // two 64-wide chunks per trip: four loads in flight per lane
+        const double u00 = col0[c], u10 = col1[c], u01 = col0[c + 64], u11 = col1[c + 64];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            const double q0 = ks[c * MC + j], q1 = ks[(c + 64) * MC + j];
+            a0[j] = __builtin_fma(u00, q0, a0[j]);
+            a1[j] = __builtin_fma(u10, q0, a1[j]);
+            a0[j] = __builtin_fma(u01, q1, a0[j]);
+            a1[j] = __builtin_fma(u11, q1, a1[j]);
+        }
+    }
+    for (; c <= k0 + 1; c += 64) {                           // the ragged end (row k0 stops one entry before row k0+1)
+        const double u0 = (c <= k0) ? col0[c] : 0.0, u1 = col1[c];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            const double q = ks[c * MC + j];
+            a0[j] = __builtin_fma(u0, q, a0[j]);
+            a1[j] = __builtin_fma(u1, q, a1[j]);
+        }
+    }
+    const double z0 = Afac[(size_t)k0 * ld + Np], z1 = Afac[(size_t)(k0 + 1) * ld + Np];
+    double ss[MC], mz[MC];
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+        double v0 = a0[j], v1 = a1[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            v0 += __shfl_xor(v0, off);
+            v1 += __shfl_xor(v1, off);
+        }
+        ss[j] = __builtin_fma(v0, v0, v1 * v1);
+        mz[j] = __builtin_fma(v0, z0, v1 * z1);
+        if (j == 0 && vout && lane == 0) {
+            vout[k0] = v0;
+            vout[k0 + 1] = v1;
+        }
+    }
+    __syncthreads();                                         // ks no longer needed: its head takes the wave partials
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < WINV_MAX_M; ++j) {
+            ks[wave * 8 + 2 * j] = (j < MC) ? ss[j < MC ? j : 0] : 0.0;
+            ks[wave * 8 + 2 * j + 1] = (j < MC) ? mz[j < MC ? j : 0] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < 8) part[(size_t)blockIdx.x * 8 + tid] = ks[tid] + ks[8 + tid] + ks[16 + tid] + ks[24 + tid];
+}
+
+// More than four candidates but fewer than fill the fused kernel (≤ 4096), again repeatedly on one
+// factorisation (multistart refinement: every iteration of HipGradientAM is such a call): with both inverse
+// factors resident the substitutions are plain GEMMs without any sequential step,
+//   inv_fwd_kernel   V = L⁻¹ K*   (A operand = the lower inverse, k range up to the row block),  Σv², v·z partials per row block
+//   inv_bwd_kernel   W = L⁻ᵀ V    (A operand = the upper inverse, k range from the row block)    — the adjoint pass of the gradients
+// on 128×32 tiles, one workgroup per (row block, candidate tile); the candidate tiles of one row block are neighbours in
+// dispatch order, so they share that row block's panel of the inverse in L2 (row-block-fastest order streamed every panel
+// from HBM once per tile: 37 TF instead of 50; 256×32 tiles were no faster).
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void inv_fwd_kernel(const double* __restrict__ Linv, int ldl, int Np,
+                                                               const double* __restrict__ Afac, int ld,
+                                                               const double* __restrict__ Kst, double* __restrict__ Vslabs,
+                                                               double* __restrict__ ssp) {
+    static_assert(GU::WC == 1 && GU::BN == 32 && GU::WR == 4, "(128 or 256)×32 tiles, four waves stacked along the rows");
+    constexpr int TM = GU::TM, TN = GU::TN, BM = GU::BM;
+    __shared__ double red[2][4][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rb = gridDim.y - 1 - blockIdx.y;               // deepest row blocks first; candidate tiles of one row block are
+                                                             // neighbours in dispatch order and share its panel of the inverse in L2
+    const int r0 = rb * BM;
+    const double* B = Kst + (size_t)blockIdx.x * Np * 32;
+    double* V = Vslabs + (size_t)blockIdx.x * Np * 32;
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    GU::template run<1>(Linv + r0, ldl, B, 32, r0 + BM, acc);
+    double ps[TN][4], pz[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ps[n][i] = pz[n][i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = r0 + GU::row_of(wave, m, lane);
+        const double zr = Afac[(size_t)row * ld + Np];
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double v = acc[m][n][i];
+                V[(size_t)row * 32 + GU::col_of(0, n, i, lane)] = v;
+                ps[n][i] = __builtin_fma(v, v, ps[n][i]);
+                pz[n][i] = __builtin_fma(v, zr, pz[n][i]);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double sv = ps[n][i], zv = pz[n][i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                sv += __shfl_xor(sv, off);
+                zv += __shfl_xor(zv, off);
+            }
+            if ((lane & 15) == 0) {
+                const int col = GU::col_of(0, n, i, lane);
+                red[0][wave][col] = sv;
+                red[1][wave][col] = zv;
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int q = threadIdx.x >> 5, col = threadIdx.x & 31;
+        ssp[((size_t)blockIdx.x * gridDim.y + rb) * 64 + threadIdx.x] = red[q][0][col] + red[q][1][col] + red[q][2][col] + red[q][3][col];
+    }
+}
+
+// Σ over the row blocks (fixed order), then μ and σ² as in few_finish_kernel
+__global__ __launch_bounds__(256) void inv_fwd_finish_kernel(const double* __restrict__ ssp, int nrb, const double* __restrict__ mean_s,
+                                                             int M, double amp2, int mode, double* __restrict__ mu,
+                                                             double* __restrict__ var) {
+    __shared__ double red[4][64];
+    const int tid = threadIdx.x, q = tid & 63, grp = tid >> 6;
+    const double* p = ssp + (size_t)blockIdx.x * nrb * 64;
+    double a = 0.0;
+    for (int rb = grp; rb < nrb; rb += 4) a += p[(size_t)rb * 64 + q];
+    red[grp][q] = a;
+    __syncthreads();
+    if (tid < 32) {
+        const int j = blockIdx.x * 32 + tid;
+        if (j < M) {
+            const double sv = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            const double zv = (red[0][32 + tid] + red[1][32 + tid]) + (red[2][32 + tid] + red[3][32 + tid]);
+            mu[j] = (mean_s ? mean_s[j] : 0.0) + zv;
+            var[j] = mode == 2 ? -sv : mode == 1 ? fmax(0.0, amp2 - sv) : amp2 - sv + PREDICT_JITTER;
+        }
+    }
+}
+
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void inv_bwd_kernel(const double* __restrict__ Uinv, int ldu, int Np,
+                                                               const double* __restrict__ Vslabs, double* __restrict__ Wslabs) {
+    static_assert(GU::WC == 1 && GU::BN == 32, "(128 or 256)×32 tiles");
+    constexpr int TM = GU::TM, TN = GU::TN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = blockIdx.y * GU::BM;                      // block 0 is the deepest here; tiles of one row block are neighbours
+    const double* V = Vslabs + (size_t)blockIdx.x * Np * 32;
+    double* W = Wslabs + (size_t)blockIdx.x * Np * 32;
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    GU::template run<1>(Uinv + r0 + (size_t)r0 * ldu, ldu, V + (size_t)r0 * 32, 32, Np - r0, acc);
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int row = r0 + GU::row_of(wave, m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) W[(size_t)row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Rank-one append on resident inverse factors (boss_gp_append with one observation, from the second append on a set
+// of hyper-parameters): with l = L⁻¹k (winv_gemv_kernel, vout), d = sqrt(k(x,x) + σ² − lᵀl), z_new = (y − m − lᵀz)/d
+//     L ← [L 0; lᵀ d] ,   L⁻¹ ← [L⁻¹ 0; −wᵀ/d  1/d] ,  w = L⁻ᵀ l
+// i.e. one pass over each inverse factor (2 × 67 MB at N = 4096) instead of sweeping the new block row through all
+// earlier panels.  The diagonal-block inverses the other kernels use (16×16, 128×128, 256×256) are the diagonal blocks
+// of L⁻¹, so the same row is patched into them.
+// ------------------------------------------------------------------------------------------
+// w_c = Σ_{r≥c} Linv[r, c] l_r  for c < N0: column c of the lower inverse is contiguous; one wave per two columns.
+__global__ __launch_bounds__(256) void linv_col_gemv_kernel(const double* __restrict__ Linv, int ldl, int N0,
+                                                            const double* __restrict__ l, double* __restrict__ w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 4 + wave) * 2;
+    if (c0 >= N0) return;
+    const double* col0 = Linv + (size_t)c0 * ldl;
+    const double* col1 = col0 + ldl;
+    const bool two = c0 + 1 < N0;
+    double a0 = 0.0, a1 = 0.0;
+    for (int r = c0 + lane; r < N0; r += 64) {
+        const double lr = l[r];
+        a0 = __builtin_fma(col0[r], lr, a0);
+        if (two && r > c0) a1 = __builtin_fma(col1[r], lr, a1);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a0 += __shfl_xor(a0, off);
+        a1 += __shfl_xor(a1, off);
+    }
+    if (lane == 0) {
+        w[c0] = a0;
+        if (two) w[c0 + 1] = a1;
+    }
+}
+
+// Σ of the gemv partials (fixed-order tree), then d, z_new; scal = {logdet, zᵀz} is advanced, dz = {d, z_new};
+// a non-positive d² is reported like a failed pivot (info = N0 + 1).
+__global__ __launch_bounds__(256) void append_scalars_kernel(const double* __restrict__ part, int nwg, const double* __restrict__ hyp,
+                                                             const double* __restrict__ y, const double* __restrict__ mean, int N0,
+                                                             double* __restrict__ scal, double* __restrict__ dz, int* __restrict__ info) {
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    double s = 0.0, z = 0.0;
+    for (int w = tid; w < nwg; w += 256) {
+        s += part[(size_t)w * 8];
+        z += part[(size_t)w * 8 + 1];
+    }
+    red[0][tid] = s;
+    red[1][tid] = z;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            red[0][tid] += red[0][tid + off];
+            red[1][tid] += red[1][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double d2 = hyp[0] + hyp[1] - red[0][0];
+        if (!(d2 > 0.0)) *info = N0 + 1;
+        const double dd = sqrt(d2), zn = (y[N0] - mean[N0] - red[1][0]) / dd;
+        dz[0] = dd;
+        dz[1] = zn;
+        scal[0] += 2.0 * log(dd);
+        scal[1] = __builtin_fma(zn, zn, scal[1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void append_write_kernel(double* __restrict__ A, int ld, int Np, int N0,
+                                                           const double* __restrict__ l, const double* __restrict__ w,
+                                                           const double* __restrict__ dz, double* __restrict__ Linv,
+                                                           double* __restrict__ U, double* __restrict__ Dinv,
+                                                           double* __restrict__ Dinv2, double* __restrict__ inv16) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c > N0) return;
+    const double dd = dz[0];
+    const bool diag = c == N0;
+    const double t = diag ? 1.0 / dd : -w[c] / dd;           // row N0 of L⁻¹
+    A[(size_t)c * ld + N0] = diag ? dd : l[c];               // row N0 of L
+    if (diag) A[(size_t)N0 * ld + Np] = dz[1];               // z_new (the δᵀ/z row block)
+    Linv[(size_t)c * ld + N0] = t;
+    U[(size_t)N0 * ld + c] = t;
+    const int b1 = N0 / BLK, b2 = N0 / PRED_RB, b16 = N0 / 16;
+    if (c >= b1 * BLK) Dinv[(size_t)b1 * BLK * BLK + (size_t)(c - b1 * BLK) * BLK + (N0 - b1 * BLK)] = t;
+    if (c >= b2 * PRED_RB) Dinv2[(size_t)b2 * PRED_RB * PRED_RB + (size_t)(c - b2 * PRED_RB) * PRED_RB + (N0 - b2 * PRED_RB)] = t;
+    if (c >= b16 * 16) inv16[(size_t)b1 * 8 * 256 + (size_t)(b16 - b1 * 8) * 256 + (c - b16 * 16) * 16 + (N0 - b16 * 16)] = t;
+}
+
+// mode: 0 plain (σ² = α² − Σv² + 1e-18), 1 gradient observations (max(0, α² − Σv²)), 2 nonstationary (−Σv²; gibbs_var_kernel follows)
+__global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restrict__ part, int nwg, int M,
+                                                          const double* __restrict__ mean_s, double amp2, int mode,
+                                                          double* __restrict__ mu, double* __restrict__ var) {
+    __shared__ double red[8][256];
+    const int tid = threadIdx.x;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (int w = tid; w < nwg; w += 256)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += part[(size_t)w * 8 + q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[q][tid] = acc[q];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {               // fixed-order tree: deterministic
+        if (tid < off)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[q][tid] += red[q][tid + off];
+        __syncthreads();
+    }
+    if (tid < M) {
+        const double s = red[2 * tid][0], z = red[2 * tid + 1][0];
+        mu[tid] = (mean_s ? mean_s[tid] : 0.0) + z;
+        var[tid] = mode == 2 ? -s : mode == 1 ? fmax(0.0, amp2 - s) : amp2 - s + PREDICT_JITTER;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 256×256 diagonal-block inverses from the 128×128 ones (prediction with 256-row steps halves the
+// V-slab re-reads and the number of dependent steps per candidate tile):
+//     inv [ A 0 ; B C ] = [ A⁻¹ 0 ; −C⁻¹ B A⁻¹  C⁻¹ ]
+// small_gemm128_kernel: C_s = alpha · A_s · B_s for 128×128 column-major operands (32×32 output
+// tile per workgroup, grid (16, pairs)); dinv_pair_assemble_kernel copies the diagonal quadrants.
+// Runs once per factorisation, off the prediction kernel's path (≈10 µs).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_gemm128_kernel(const double* __restrict__ Abase, int lda, size_t sA,
+                                                            const double* __restrict__ Bbase, int ldb, size_t sB,
+                                                            double* __restrict__ Cbase, int ldc, size_t sC, double alpha) {
+    __shared__ double As[32][33], Bs[32][33];
+    const double* A = Abase + (size_t)blockIdx.y * sA;
+    const double* B = Bbase + (size_t)blockIdx.y * sB;
+    double* C = Cbase + (size_t)blockIdx.y * sC;
+    const int r0 = (blockIdx.x & 3) * 32, c0 = (blockIdx.x >> 2) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // ty 0..7 → 4 columns each
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < BLK; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[ty * 4 + j][tx] = A[(size_t)(k0 + ty * 4 + j) * lda + r0 + tx];      // As[k][r]
+            Bs[ty * 4 + j][tx] = B[(size_t)(c0 + ty * 4 + j) * ldb + k0 + tx];      // Bs[c][k]
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const double a = As[kk][tx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fma(a, Bs[ty * 4 + j][kk], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) C[(size_t)(c0 + ty * 4 + j) * ldc + r0 + tx] = alpha * acc[j];
+}
+
+// Dinv2_p (256×256, column-major): diagonal quadrants = Dinv128 of blocks 2p, 2p+1; upper right = 0.
+__global__ __launch_bounds__(256) void dinv_pair_assemble_kernel(const double* __restrict__ Dinv128,
+                                                                 double* __restrict__ Dinv2) {
+    const int p = blockIdx.y, c = blockIdx.x;                     // column c of the 256×256 block
+    const double* src = Dinv128 + (size_t)(2 * p + (c >> 7)) * BLK * BLK + (size_t)(c & 127) * BLK;
+    double* dst = Dinv2 + (size_t)p * 4 * BLK * BLK + (size_t)c * 2 * BLK;
+    const int r = threadIdx.x;                                    // 0..255
+    if (c < BLK) {
+        if (r < BLK) dst[r] = src[r];                             // lower-left quadrant is written by the GEMM
+    } else {
+        dst[r] = (r < BLK) ? 0.0 : src[r - BLK];
+    }
+}
+
+}  // namespace boss
