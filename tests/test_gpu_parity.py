@@ -947,7 +947,7 @@ def test_few_candidates_path(api, O, N, M):
     g.close()
 
 
-@pytest.mark.parametrize("N,M", [(1024, 1), (1300, 3), (2048, 4), (4096, 1), (1024, 20), (1300, 33), (2048, 200)])
+@pytest.mark.parametrize("N,M", [(1024, 1), (1300, 3), (2048, 4), (4096, 1), (1024, 20), (1300, 33), (2048, 200), (6000, 1), (6000, 2)])
 def test_repeated_few_candidate_calls_use_the_explicit_inverse(api, O, N, M):
     """One to four candidates per call, many calls per posterior (the reference's `acq.(eachcol(xs))` pattern): from
     the second call on a factorisation the handle predicts through the explicit L⁻ᵀ.  Every call agrees with the
