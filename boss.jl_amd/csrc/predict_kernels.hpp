@@ -184,23 +184,54 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
 //   few_update_kernel   R_j −= L[j, i] V_i for every later row block j                       — one workgroup per 128 rows
 // Two short launches per step instead of one long-running workgroup.
 // ------------------------------------------------------------------------------------------
+constexpr int WINV_MAX_M_DECL = 4;                            // = WINV_MAX_M (defined with the one-pass kernel below)
+constexpr int KSTAR_LDS_EXTRA = 8 * 256;                      // doubles: row coordinates of 8 dimensions × 256 rows
 __global__ __launch_bounds__(256) void kstar_rows_kernel(const double* __restrict__ Xsc, int Np, int N,
                                                          const double* __restrict__ Csc, int d, int Mp, int kern,
                                                          double amp2, double* __restrict__ kst, int ncols) {
     // ncols: columns of the 32-wide tile that are needed (the one-to-four-candidates path reads only the first ones)
-    extern __shared__ double cs[];                           // [d][32]
+    extern __shared__ double cs[];                           // [d][32] candidate coordinates | [8][256] row coordinates
     const int c0 = blockIdx.y * 32;                          // candidate tile
     kst += (size_t)blockIdx.y * Np * 32;
     for (int idx = threadIdx.x; idx < d * 32; idx += 256) cs[idx] = Csc[(size_t)(idx >> 5) * Mp + c0 + (idx & 31)];
+    if (ncols == 32) {
+        // full tile: lane = candidate column, so that a wave writes two whole 256-byte rows of the tile per store
+        // (one row per thread made every store touch 64 different cache lines: 244 µs for 128 tiles, now ≈ 40)
+        double* xs = cs + d * 32;
+        const int col = threadIdx.x & 31, rg = threadIdx.x >> 5, rbase = blockIdx.x * 256;
+        double r2[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) r2[i] = 0.0;
+        for (int k0 = 0; k0 < d; k0 += 8) {
+            const int kc = (d - k0 < 8) ? d - k0 : 8;
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < kc * 256; idx += 256) xs[idx] = Xsc[(size_t)(k0 + (idx >> 8)) * Np + rbase + (idx & 255)];
+            __syncthreads();
+            for (int kk = 0; kk < kc; ++kk) {
+                const double cv = cs[(k0 + kk) * 32 + col];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const double df = xs[kk * 256 + rg + 8 * i] - cv;
+                    r2[i] = __builtin_fma(df, df, r2[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int row = rbase + rg + 8 * i;
+            kst[(size_t)row * 32 + col] = (row < N) ? amp2 * kappa_r2(kern, r2[i]) : 0.0;
+        }
+        return;
+    }
     __syncthreads();
     const int row = blockIdx.x * 256 + threadIdx.x;
-    double r2[32];
+    double r2[WINV_MAX_M_DECL];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) r2[c] = 0.0;
+    for (int c = 0; c < WINV_MAX_M_DECL; ++c) r2[c] = 0.0;
     for (int kd = 0; kd < d; ++kd) {
         const double xr = Xsc[(size_t)kd * Np + row];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
+        for (int c = 0; c < WINV_MAX_M_DECL; ++c) {
             if (c < ncols) {
                 const double df = xr - cs[kd * 32 + c];
                 r2[c] = __builtin_fma(df, df, r2[c]);
@@ -209,7 +240,7 @@ __global__ __launch_bounds__(256) void kstar_rows_kernel(const double* __restric
     }
     const bool live = row < N;
 #pragma unroll
-    for (int c = 0; c < 32; ++c)
+    for (int c = 0; c < WINV_MAX_M_DECL; ++c)
         if (c < ncols) kst[(size_t)row * 32 + c] = live ? amp2 * kappa_r2(kern, r2[c]) : 0.0;
 }
 
@@ -338,7 +369,7 @@ __global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* _
 // instead of 16 dependent substitution steps.  Per-workgroup partials of Σv², v·z are summed in a fixed order.
 // ------------------------------------------------------------------------------------------
 constexpr int WINV_ROWS = 8;                                  // rows k per workgroup (two per wave)
-constexpr int WINV_MAX_M = 4;
+constexpr int WINV_MAX_M = WINV_MAX_M_DECL;
 template <int MC>                                            // candidates staged per call: 1, 2 or 4
 __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict__ U, int ldu, int Np,
                                                         const double* __restrict__ Afac, int ld,
