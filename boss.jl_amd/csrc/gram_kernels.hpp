@@ -293,6 +293,55 @@ __global__ __launch_bounds__(256) void gibbs_kstar_kernel(const double* __restri
     }
 }
 
+// The same for 32-wide tiles with the lanes along the candidate columns: a wave writes two whole 256-byte rows of the
+// tile per store (one row per thread makes every store touch 64 cache lines).  Rows are staged 8 dimensions at a time.
+constexpr int GIBBS_KSTAR_MAX_D = 48;                         // LDS: (2·d·32 + 32 + 2·8·256) doubles
+__global__ __launch_bounds__(256) void gibbs_kstar_cols_kernel(const double* __restrict__ X, const double* __restrict__ Lam,
+                                                               const double* __restrict__ amp, int d, int N, int Np,
+                                                               const double* __restrict__ C, const double* __restrict__ Clam,
+                                                               const double* __restrict__ Camp, int Mp, double* __restrict__ out) {
+    extern __shared__ double sm[];                           // cx[d][32] | cl[d][32] | ca[32] | xs[8][256] | ls[8][256]
+    double* cx = sm;
+    double* cl = cx + d * 32;
+    double* ca = cl + d * 32;
+    double* xs = ca + 32;
+    double* ls = xs + 8 * 256;
+    const int tid = threadIdx.x, c0 = blockIdx.y * 32, col = tid & 31, rg = tid >> 5, rbase = blockIdx.x * 256;
+    out += (size_t)blockIdx.y * Np * 32;
+    for (int idx = tid; idx < d * 32; idx += 256) {
+        cx[idx] = C[(size_t)(idx >> 5) * Mp + c0 + (idx & 31)];
+        cl[idx] = Clam[(size_t)(idx >> 5) * Mp + c0 + (idx & 31)];
+    }
+    if (tid < 32) ca[tid] = Camp[c0 + tid];
+    double pr[32], es[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        pr[i] = 1.0;
+        es[i] = 0.0;
+    }
+    for (int k0 = 0; k0 < d; k0 += 8) {
+        const int kc = (d - k0 < 8) ? d - k0 : 8;
+        __syncthreads();
+        for (int idx = tid; idx < kc * 256; idx += 256) {
+            xs[idx] = X[(size_t)(k0 + (idx >> 8)) * Np + rbase + (idx & 255)];
+            ls[idx] = Lam[(size_t)(k0 + (idx >> 8)) * Np + rbase + (idx & 255)];
+        }
+        __syncthreads();
+        for (int kk = 0; kk < kc; ++kk) {
+            const double xc = cx[(k0 + kk) * 32 + col], lc = cl[(k0 + kk) * 32 + col];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) gibbs_dim(xc, lc, xs[kk * 256 + rg + 8 * i], ls[kk * 256 + rg + 8 * i], pr[i], es[i]);
+        }
+    }
+    const double ac = ca[col];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int row = rbase + rg + 8 * i;
+        const double am = 0.5 * (amp[row] + ac);
+        out[(size_t)row * 32 + col] = (row < N) ? am * am * sqrt(pr[i]) * exp(-es[i]) : 0.0;
+    }
+}
+
 // σ²(x*) = k(x*,x*) − Σv² + 1e-18 with k(x*,x*) = α(x*)²; the substitution kernels left −Σv² in var.
 __global__ void gibbs_var_kernel(double* __restrict__ var, const double* __restrict__ Camp, int M) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
