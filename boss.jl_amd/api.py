@@ -49,6 +49,8 @@ SIGNATURES = {
     "boss_gp_get_factor": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
     "boss_gp_loglike_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
                                         C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
+    "boss_gp_loglike_grad_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
+                                             C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
     "boss_gp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_gp_predict_grad": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
                                        C.POINTER(C.c_long)]),
@@ -462,9 +464,11 @@ def fit(X, y, kernel, lengthscale, amplitude, noise_std, mean_X=None, discrete=N
     return g
 
 
-def loglike_batch(X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=None, discrete=None, device: int = 0):
+def loglike_batch(X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=None, discrete=None, device: int = 0,
+                  want_grad: bool = False):
     """S log marginal likelihoods on the same (X, y) slice; lengthscales is d×S.
-    Returns (ll[S], status[S]); ll = -Inf where the matrix is not PD (safe_data_loglike)."""
+    Returns (ll[S], status[S]); ll = -Inf where the matrix is not PD (safe_data_loglike).
+    want_grad: additionally grad[(d+2), S] = ∂ll/∂(lengthscale[d], amplitude, noise_std) per set -> (ll, status, grad)."""
     X = _f64(X, 2)
     y = _f64(np.asarray(y).reshape(-1), 1)
     lam = _f64(lengthscales, 2)
@@ -486,6 +490,12 @@ def loglike_batch(X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=Non
     disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
     ll = np.zeros(S)
     st = np.zeros(S, dtype=np.int32)
+    if want_grad:
+        grad = np.zeros((d + 2, S), order="F")
+        _check(load_library().boss_gp_loglike_grad_batch(device, _kernel_id(kernel), d, N, _dp(X), _dp(y), _dp(m), stride,
+                                                         _ucp(disc), S, _dp(lam), _dp(amp), _dp(sig), _dp(ll), _dp(grad),
+                                                         st.ctypes.data_as(C.POINTER(C.c_int))))
+        return ll, st, grad
     _check(load_library().boss_gp_loglike_batch(device, _kernel_id(kernel), d, N, _dp(X), _dp(y), _dp(m), stride,
                                                 _ucp(disc), S, _dp(lam), _dp(amp), _dp(sig), _dp(ll),
                                                 st.ctypes.data_as(C.POINTER(C.c_int))))

@@ -65,8 +65,8 @@ class HipGradientMAP:
     """OptimizationMAP semantics (src/model_fitters/optimization.jl:13-164): multistart local maximisation
     of the log-posterior  loglike(data | θ) + logprior(θ)  over the GP hyper-parameters, the best local
     optimum wins.  The reference hands the objective to an Optimization.jl algorithm with automatic
-    differentiation; here every evaluation is one device call per output — boss_gp_update (value) +
-    boss_gp_loglike_grad (analytic gradient) on resident data — and the ascent runs in log-parameter space
+    differentiation; here the starts advance in lockstep and every round is ONE device call per output —
+    boss_gp_loglike_grad_batch: values and analytic gradients of all trial points — and the ascent runs in log-parameter space
     (the reference softplus/log-transforms positive parameters the same way, :120-144) with a
     Barzilai–Borwein-free backtracking step.  Parameters with a Dirac prior stay fixed (dirac.jl:36-77).
     Multi-GPU: the starts are sharded across ranks, 16-byte arg-max exchange (as HipBatchedMAP)."""
@@ -77,23 +77,26 @@ class HipGradientMAP:
     step0: float = 0.3
     starts: Optional[List[HipGPParams]] = None       # set_starts (optimization.jl): given starts replace the prior draws
 
-    def _objective(self, model, prior_ll, gps, data, p: HipGPParams):
-        """(log-posterior, gradient w.r.t. (λ[d,P], α[P], σ[P])) — gradient of the data term from the device."""
-        d, P = p.lengthscales.shape
-        tot = prior_ll(p)
-        gl, ga, gs = np.zeros((d, P)), np.zeros(P), np.zeros(P)
-        if not np.isfinite(tot):
-            return -np.inf, gl, ga, gs
-        for i, g in enumerate(gps):
-            try:
-                tot += g.update(p.lengthscales[:, i], p.amplitudes[i], p.noise_std[i], model.mean_values(data.X, p, i))
-            except api.PosDefException:
-                return -np.inf, gl, ga, gs
-            _, gr = g.loglike_grad()
-            gl[:, i], ga[i], gs[i] = gr[:d], gr[d], gr[d + 1]
-            gl[:, i] += np.atleast_1d(model.lengthscale_priors[i].grad_logpdf(p.lengthscales[:, i]))
-            ga[i] += model.amplitude_priors[i].grad_logpdf(p.amplitudes[i])
-            gs[i] += model.noise_std_priors[i].grad_logpdf(p.noise_std[i])
+    def _objective_batch(self, model, prior_ll, data, plist: List[HipGPParams]):
+        """log-posterior and its gradient w.r.t. (λ[d,P], α[P], σ[P]) for every parameter set of `plist`: one batched
+        device call per output (boss_gp_loglike_grad_batch) — all starts of a round advance together."""
+        S = len(plist)
+        d, P = plist[0].lengthscales.shape
+        tot = np.array([prior_ll(p) for p in plist], dtype=float)
+        gl, ga, gs = np.zeros((S, d, P)), np.zeros((S, P)), np.zeros((S, P))
+        for i in range(P):
+            lam = np.stack([p.lengthscales[:, i] for p in plist], axis=1)
+            amp = np.array([p.amplitudes[i] for p in plist])
+            sig = np.array([p.noise_std[i] for p in plist])
+            ll, st, gr = api.loglike_batch(data.X, data.Y[i], model.kernel, lam, amp, sig, model.mean_values(data.X, None, i),
+                                           model.discrete, model.device, want_grad=True)
+            tot += np.where(st == 0, ll, -np.inf)
+            gl[:, :, i], ga[:, i], gs[:, i] = gr[:d].T, gr[d], gr[d + 1]
+            for k, p in enumerate(plist):
+                gl[k, :, i] += np.atleast_1d(model.lengthscale_priors[i].grad_logpdf(p.lengthscales[:, i]))
+                ga[k, i] += model.amplitude_priors[i].grad_logpdf(p.amplitudes[i])
+                gs[k, i] += model.noise_std_priors[i].grad_logpdf(p.noise_std[i])
+        tot = np.where(np.isfinite(tot), tot, -np.inf)
         return tot, gl, ga, gs
 
     def estimate_parameters(self, problem: BossProblem, options: BossOptions = BossOptions(), return_all: bool = False):
@@ -114,40 +117,46 @@ class HipGradientMAP:
         free_l = np.array([not isinstance(pr, (Dirac, MvDirac)) for pr in model.lengthscale_priors])
         free_a = np.array([not isinstance(pr, Dirac) for pr in model.amplitude_priors])
         free_s = np.array([not isinstance(pr, Dirac) for pr in model.noise_std_priors])
-        gps = [api.GP(data.X, data.Y[i], model.kernel, model.discrete, model.device) for i in range(P)]
         results = []
-        try:
-            for k in range(lo, hi):
-                p = starts[k]
-                f, gl, ga, gs = self._objective(model, prior_ll, gps, data, p)
-                step = self.step0
-                for _ in range(self.iters):
-                    if not np.isfinite(f):
-                        break
+        if hi > lo:
+            # every start runs the same backtracking ascent it would run alone; the starts advance in lockstep so that each
+            # round's trial points are evaluated by ONE batched device call per output
+            ps = [starts[k] for k in range(lo, hi)]
+            f, gl, ga, gs = self._objective_batch(model, prior_ll, data, ps)
+            n = len(ps)
+            step = np.full(n, self.step0)
+            its = np.zeros(n, dtype=int)
+            alive = np.isfinite(f) & (self.iters > 0)
+            while alive.any():
+                idx, trial = [], []
+                for k in np.flatnonzero(alive):
+                    p = ps[k]
                     # ascent direction in log-space: ∂f/∂log θ = θ ∂f/∂θ ; fixed (Dirac) parameters do not move
-                    dl = np.where(free_l[None, :], p.lengthscales * gl, 0.0)
-                    da = np.where(free_a, p.amplitudes * ga, 0.0)
-                    ds = np.where(free_s, p.noise_std * gs, 0.0)
+                    dl = np.where(free_l[None, :], p.lengthscales * gl[k], 0.0)
+                    da = np.where(free_a, p.amplitudes * ga[k], 0.0)
+                    ds = np.where(free_s, p.noise_std * gs[k], 0.0)
                     nrm = math.sqrt(float((dl * dl).sum() + (da * da).sum() + (ds * ds).sum()))
                     if nrm < 1e-10:
-                        break
-                    accepted = False
-                    while step > 1e-6:
-                        q = HipGPParams(p.lengthscales * np.exp(step * dl / nrm), p.amplitudes * np.exp(step * da / nrm),
-                                        p.noise_std * np.exp(step * ds / nrm), p.theta)
-                        fq, glq, gaq, gsq = self._objective(model, prior_ll, gps, data, q)
-                        if fq > f:
-                            p, f, gl, ga, gs = q, fq, glq, gaq, gsq
-                            step = min(step * 1.6, 2.0)
-                            accepted = True
-                            break
-                        step *= 0.4
-                    if not accepted:
-                        break
-                results.append((k, p, float(f)))
-        finally:
-            for g in gps:
-                g.close()
+                        alive[k] = False
+                        continue
+                    idx.append(k)
+                    trial.append(HipGPParams(p.lengthscales * np.exp(step[k] * dl / nrm), p.amplitudes * np.exp(step[k] * da / nrm),
+                                             p.noise_std * np.exp(step[k] * ds / nrm), p.theta))
+                if not idx:
+                    break
+                fq, glq, gaq, gsq = self._objective_batch(model, prior_ll, data, trial)
+                for j, k in enumerate(idx):
+                    if fq[j] > f[k]:
+                        ps[k], f[k], gl[k], ga[k], gs[k] = trial[j], fq[j], glq[j], gaq[j], gsq[j]
+                        step[k] = min(step[k] * 1.6, 2.0)
+                        its[k] += 1
+                        if its[k] >= self.iters:
+                            alive[k] = False
+                    else:
+                        step[k] *= 0.4
+                        if step[k] <= 1e-6:
+                            alive[k] = False
+            results = [(lo + k, ps[k], float(f[k])) for k in range(n)]
         if return_all:
             return [MAPParams(p, f) for _, p, f in results]
         best = max(results, key=lambda r: (r[2], -r[0])) if results else None

@@ -181,6 +181,14 @@ int boss_gp_loglike_batch(int device, int kernel, int d, int N, const double* X,
                           const double* mean_X, int mean_stride, const unsigned char* discrete,
                           int S, const double* lengthscales, const double* amplitudes,
                           const double* noise_stds, double* ll_out, int* status_out);
+/* The same with the gradient of every log-likelihood w.r.t. (lengthscale[d], amplitude, noise_std):
+ * grad_out is (d+2)×S (column s = set s; zeros where the status is not BOSS_OK).  Replaces the S value-and-gradient
+ * evaluations one round of a multistart OptimizationMAP makes (src/model_fitters/optimization.jl:146-164, gradients by
+ * automatic differentiation there).  The factorisations run batched; d <= 32. */
+int boss_gp_loglike_grad_batch(int device, int kernel, int d, int N, const double* X, const double* y,
+                               const double* mean_X, int mean_stride, const unsigned char* discrete,
+                               int S, const double* lengthscales, const double* amplitudes,
+                               const double* noise_stds, double* ll_out, double* grad_out, int* status_out);
 
 /* ---- prediction -------------------------------------------------------------------------
  * Replaces: mean_and_var(post, X::Matrix) (gaussian_process.jl:174-178) =

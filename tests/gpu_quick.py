@@ -221,6 +221,19 @@ def append_fast_timing(d=8, N=4000, count=40):
     g.close()
 
 
+def llgrad_batch_timing(d=8, N=4096):
+    X, y, _ = problem(d, N, 1)
+    rng = np.random.default_rng(0)
+    for S in (1, 4, 8, 16):
+        lam = rng.uniform(0.4, 0.6, (d, S)); amp = rng.uniform(0.9, 1.1, S); sig = np.full(S, 0.05)
+        api.loglike_batch(X, y, "matern52", lam, amp, sig, want_grad=True)
+        t = time.time()
+        for _ in range(3):
+            api.loglike_batch(X, y, "matern52", lam, amp, sig, want_grad=True)
+        dt = (time.time() - t) / 3
+        print(f"batched loglike + gradient N={N} S={S}: {dt*1e3:.2f} ms per call = {dt/S*1e3:.2f} ms per set ({S/dt:.0f} /s)", flush=True)
+
+
 def few_timing(d=8, N=4096):
     """The reference's call pattern: one candidate per call."""
     X, y, Xs = problem(d, N, 64)
@@ -412,6 +425,8 @@ if __name__ == "__main__":
         ggp_timing(n=int(os.environ.get("GGP_N", "1024")))
     if "append_fast" in stages:
         append_fast_timing()
+    if "llgrad_batch" in stages:
+        llgrad_batch_timing()
     if "ngp" in stages:
         ngp_timing()
     if "parity_big" in stages:

@@ -1510,3 +1510,31 @@ def test_rank_one_appends_on_resident_inverses(api, O, N0, count):
     assert abs(lp - O.gp_fit(Xa, ya, "matern52", lam * 1.2, 1.0, 0.06, mean=ma).logpdf) <= 1e-9 * (1 + abs(lp))
     tr.close()
     g.close()
+
+
+@pytest.mark.parametrize("d,N,S", [(1, 7, 3), (3, 200, 5), (8, 700, 9), (4, 1300, 4)])
+def test_batched_likelihood_gradients(api, O, d, N, S):
+    """boss_gp_loglike_grad_batch: values and gradients of S hyper-parameter sets in one call (batched factorisations,
+    gradient passes on shared workspaces) equal the oracle's and the single-handle entry points', with per-set means,
+    an invalid set and discrete dimensions."""
+    rng = np.random.default_rng(N + S)
+    disc = None if d < 3 else np.array([False] * (d - 1) + [True])
+    scale = 5.0 if disc is not None else 1.0
+    X = rng.uniform(0, scale, (d, N))
+    y = np.sin(3 * X / scale).sum(0) + 0.05 * rng.standard_normal(N)
+    lam = rng.uniform(0.3, 0.9, (d, S)) * scale
+    amp, sig = rng.uniform(0.7, 1.4, S), rng.uniform(0.03, 0.1, S)
+    means = np.stack([0.1 * X[0] + 0.01 * k for k in range(S)])
+    sig[S - 1] = -1.0                                        # invalid set: status INVALID, ll = -Inf, zero gradient
+    ll, st, grad = api.loglike_batch(X, y, "matern52", lam, amp, sig, means, disc, want_grad=True)
+    assert grad.shape == (d + 2, S)
+    for k in range(S - 1):
+        ll_o, gr_o = O.gp_data_loglike_grad(X, y, "matern52", lam[:, k], amp[k], sig[k], mean=means[k], discrete=disc)
+        assert st[k] == 0 and abs(ll[k] - ll_o) <= 1e-9 * (1 + abs(ll_o))
+        assert np.allclose(grad[:, k], gr_o, rtol=0, atol=1e-8 * (1 + np.abs(gr_o).max())), k
+    assert st[S - 1] == api.BOSS_E_INVALID and ll[S - 1] == -np.inf and np.all(grad[:, S - 1] == 0.0)
+    g = api.GP(X, y, "matern52", disc)
+    g.update(lam[:, 0], amp[0], sig[0], means[0])
+    _, gr1 = g.loglike_grad()
+    assert np.allclose(grad[:, 0], gr1, rtol=0, atol=1e-10 * (1 + np.abs(gr1).max()))
+    g.close()
