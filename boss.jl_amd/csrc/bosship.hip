@@ -78,7 +78,9 @@ struct Ctx {
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
-    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC, few;   // lg*: log-likelihood gradient (LinvT, K⁻¹, partials)   // craw: raw candidates of one-shot calls
+    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC, few, lgA2, lgB2, lgC2;   // lg*2: second bank (batched gradients, side stream)
+    hipEvent_t ev_join = nullptr;
+    //   // lg*: log-likelihood gradient (LinvT, K⁻¹, partials)   // craw: raw candidates of one-shot calls
     void* pinned = nullptr;   // small host-pinned result area
     std::mutex mtx;
 };
@@ -113,6 +115,7 @@ static int get_ctx(int device, Ctx** out) {
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->lookahead = !(getenv("BOSS_NO_LOOKAHEAD") && atoi(getenv("BOSS_NO_LOOKAHEAD")));
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
     // kernels that need more than 64 KiB of dynamic LDS
