@@ -98,8 +98,16 @@ for case in range(first, ncases):
                 amps, sigs = rng.uniform(0.7, 1.5, S), rng.uniform(0.03, 0.1, S)
                 per_set_mean = use_mean and rng.random() < 0.5
                 mX = None if not use_mean else (np.stack([mfun(X) + 0.01 * k for k in range(S)]) if per_set_mean else mfun(X))
-                ll, st = api.loglike_batch(X, y, kern, lams, amps, sigs, mX, disc)
+                with_grad = d <= 32 and rng.random() < 0.5
+                if with_grad:
+                    ll, st, gb = api.loglike_batch(X, y, kern, lams, amps, sigs, mX, disc, want_grad=True)
+                else:
+                    ll, st = api.loglike_batch(X, y, kern, lams, amps, sigs, mX, disc)
                 e = 0.0
+                for k in range(min(S, 2) if with_grad else 0):
+                    mk = None if mX is None else (mX[k] if per_set_mean else mX)
+                    _, gr_o = O.gp_data_loglike_grad(X, y, kern, lams[:, k], amps[k], sigs[k], mean=mk, discrete=disc)
+                    e = max(e, np.abs(gb[:, k] - gr_o).max() / (1 + np.abs(gr_o).max()) / 10)
                 for k in range(S):
                     mk = None if mX is None else (mX[k] if per_set_mean else mX)
                     want = O.gp_data_loglike_slice(X, y, kern, lams[:, k], amps[k], sigs[k], mean=mk, discrete=disc)
