@@ -78,8 +78,13 @@ struct Ctx {
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
-    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC, few, lgA2, lgB2, lgC2;   // lg*2: second bank (batched gradients, side stream)
-    hipEvent_t ev_join = nullptr;
+    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC, few;
+    // batched likelihood gradients: the gradient passes of consecutive sets rotate over LLG_BANKS streams, each with its
+    // own bank of workspaces (bank 0 = the main stream and lgA/lgB/lgC)
+    static constexpr int LLG_BANKS = 4;
+    Workspace lgbank[LLG_BANKS - 1][3];
+    hipStream_t llg_stream[LLG_BANKS - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t llg_join[LLG_BANKS - 1] = {nullptr, nullptr, nullptr};
     //   // lg*: log-likelihood gradient (LinvT, K⁻¹, partials)   // craw: raw candidates of one-shot calls
     void* pinned = nullptr;   // small host-pinned result area
     std::mutex mtx;
@@ -115,7 +120,10 @@ static int get_ctx(int device, Ctx** out) {
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    for (int i = 0; i < Ctx::LLG_BANKS - 1; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&c->llg_stream[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->llg_join[i], hipEventDisableTiming));
+    }
     c->lookahead = !(getenv("BOSS_NO_LOOKAHEAD") && atoi(getenv("BOSS_NO_LOOKAHEAD")));
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
     // kernels that need more than 64 KiB of dynamic LDS
