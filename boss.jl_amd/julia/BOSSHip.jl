@@ -188,6 +188,19 @@ function loglike_and_grad!(h::Ptr{Cvoid}, λ::Vector{Float64}, α::Float64, σ::
     check(ccall((:boss_gp_loglike_grad, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), h, C_NULL, g))
     return lp[], g            # g = [∂/∂λ_1 … ∂/∂λ_d, ∂/∂α, ∂/∂σ]; add the priors' gradients and chain through the bijector
 end
+# all starts of a multistart fit per round: values and gradients of S hyper-parameter sets of output slice i in one call
+function loglike_and_grad_batch(m::HipGaussianProcess, data::BOSS.ExperimentData, i::Int, λ::Matrix{Float64} #= d×S =#,
+                                α::Vector{Float64}, σ::Vector{Float64})
+    X = Matrix{Float64}(data.X); d, N = size(X); S = length(α)
+    ll = Vector{Float64}(undef, S); g = Matrix{Float64}(undef, d + 2, S); st = Vector{Cint}(undef, S)
+    mu = BOSS.mean_getindex(m.gp.mean, i)
+    check(ccall((:boss_gp_loglike_grad_batch, lib), Cint,
+        (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
+         Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
+        m.device, kernel_id(m.gp.kernel), d, N, X, Vector{Float64}(data.Y[i, :]), mean_vals(mu, X), 0,
+        discrete_flags(m.gp.kernel), S, λ, α, σ, ll, g, st))
+    return ll, g, st          # ll[s] = -Inf and g[:, s] = 0 where st[s] != 0 (not PD / invalid parameters)
+end
 # ---------------------------------------------------------------- GradientGaussianProcess (values + gradients)
 # BOSS.GradientGaussianProcess with the n(1+d) augmented system on the device; data::BOSS.GradientData.
 struct HipGradientGaussianProcess{G<:BOSS.GradientGaussianProcess} <: BOSS.SurrogateModel
