@@ -242,7 +242,12 @@ struct boss_track {                            // resident predictive state of (
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-static void linv_enqueue(boss_gp* g, hipStream_t s, double* U, double* Lw);
+// a batch of nb equally shaped posteriors laid out with constant strides (the batched likelihood gradient); nb = 1: one handle
+struct SetBatch {
+    int nb = 1;
+    size_t sA = 0, sInv16 = 0, sDinv = 0, sDinv2 = 0, sW = 0, sX = 0;
+};
+static void linv_enqueue(boss_gp* g, hipStream_t s, double* U, double* Lw, const SetBatch& B = SetBatch());
 // largest system the entry points accept: element offsets into the factor stay below 2^31 (exercised up to
 // 36 864 rows = 10.9 GB by the tests)
 constexpr int MAX_ROWS = 46080;

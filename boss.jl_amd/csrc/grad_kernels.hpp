@@ -435,8 +435,12 @@ __global__ __launch_bounds__(G::NTHREADS) void linvt_kernel(const double* __rest
 // Seeded with the 256×256 diagonal inverses (Dinv2), then chunk sizes s = 256, 512, … ; one launch per phase and level,
 // grid.y = pair of chunks (the last pair may be ragged or absent: Np/256 need not be a power of two).
 __global__ __launch_bounds__(256) void linv_seed_kernel(const double* __restrict__ Dinv2, double* __restrict__ Lw, int ldw,
-                                                        double* __restrict__ U, int ldu) {
+                                                        double* __restrict__ U, int ldu, size_t zD2, size_t zW) {
+    // blockIdx.z: matrix of a batch (strides zD2 for the diagonal inverses, zW for both work matrices)
     const int b = blockIdx.y, c = blockIdx.x, r = threadIdx.x;
+    Dinv2 += (size_t)blockIdx.z * zD2;
+    Lw += (size_t)blockIdx.z * zW;
+    U += (size_t)blockIdx.z * zW;
     const double v = (r >= c) ? Dinv2[(size_t)b * PRED_RB * PRED_RB + r + (size_t)c * PRED_RB] : 0.0;   // upper half holds scratch
     const size_t o = (size_t)b * PRED_RB;
     Lw[(o + r) + (o + c) * ldw] = v;
@@ -445,7 +449,11 @@ __global__ __launch_bounds__(256) void linv_seed_kernel(const double* __restrict
 
 template <class SG, int PHASE>
 __global__ __launch_bounds__(256, 2) void linv_level_kernel(const double* __restrict__ Afac, int ld, double* __restrict__ Lw,
-                                                            int ldw, double* __restrict__ U, int ldu, int Np, int s) {
+                                                            int ldw, double* __restrict__ U, int ldu, int Np, int s, size_t zA,
+                                                            size_t zW) {
+    Afac += (size_t)blockIdx.z * zA;                         // blockIdx.z: matrix of a batch
+    Lw += (size_t)blockIdx.z * zW;
+    U += (size_t)blockIdx.z * zW;
     const int a0 = 2 * blockIdx.y * s, c0 = a0 + s;
     if (c0 >= Np) return;                                    // unpaired last chunk
     const int sC = (Np - c0 < s) ? Np - c0 : s;
@@ -495,7 +503,9 @@ __global__ __launch_bounds__(256, 2) void linv_level_kernel(const double* __rest
 
 template <class SG>
 __global__ __launch_bounds__(256, 2) void kinv_syrk_kernel(const double* __restrict__ LinvT, int ldt, int Np,
-                                                           double* __restrict__ Kinv, int ldk) {
+                                                           double* __restrict__ Kinv, int ldk, size_t zW) {
+    LinvT += (size_t)blockIdx.z * zW;                        // blockIdx.z: matrix of a batch
+    Kinv += (size_t)blockIdx.z * zW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / SG::WC, wc = wave % SG::WC;
     const int t = blockIdx.x;
@@ -525,7 +535,10 @@ __global__ __launch_bounds__(256, 2) void kinv_syrk_kernel(const double* __restr
 // partial[chunk][i] = Σ_{k in chunk} LinvT[i, k] z_k   (z_k in row Np of the factor array; k < N)
 __global__ __launch_bounds__(256) void avec_partial_kernel(const double* __restrict__ LinvT, int ldt, int Np, int N,
                                                            const double* __restrict__ A, int ld,
-                                                           double* __restrict__ partial) {
+                                                           double* __restrict__ partial, size_t zW, size_t zA, size_t zP) {
+    LinvT += (size_t)blockIdx.z * zW;                        // blockIdx.z: matrix of a batch
+    A += (size_t)blockIdx.z * zA;
+    partial += (size_t)blockIdx.z * zP;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int nch = gridDim.y, ch = blockIdx.y;
     const int kbeg0 = (blockIdx.x * 256 / PRED_RB) * PRED_RB;     // first written column of these rows
@@ -539,9 +552,16 @@ __global__ __launch_bounds__(256) void avec_partial_kernel(const double* __restr
 constexpr int LLG_MAX_D = 32;
 // out[tile][0..d-1] = Σ_{i>j in tile} G_ij α² h(r_ij) Δu²_ij,m ;  out[tile][d] = Σ_i K⁻¹_ii , out[tile][d+1] = Σ_i a_i²  (diagonal tiles)
 __global__ __launch_bounds__(256) void llgrad_tile_kernel(const double* __restrict__ Xsc, int d, int N, int Np, int kern,
-                                                          double amp2, const double* __restrict__ Kinv, int ldk,
+                                                          const double* __restrict__ amp2p, int amp2_stride,
+                                                          const double* __restrict__ Kinv, int ldk,
                                                           const double* __restrict__ apart, int nch,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, size_t zX, size_t zW, size_t zP, size_t zO) {
+    // blockIdx.z: matrix of a batch; α² of that matrix at amp2p[z · amp2_stride]
+    const double amp2 = amp2p[(size_t)blockIdx.z * amp2_stride];
+    Xsc += (size_t)blockIdx.z * zX;
+    Kinv += (size_t)blockIdx.z * zW;
+    apart += (size_t)blockIdx.z * zP;
+    out += (size_t)blockIdx.z * zO;
     __shared__ double xj[LLG_MAX_D][64];
     __shared__ double aj[64];
     __shared__ double red[256];
@@ -608,7 +628,9 @@ __global__ __launch_bounds__(256) void llgrad_tile_kernel(const double* __restri
 }
 
 __global__ __launch_bounds__(256) void llgrad_reduce_kernel(const double* __restrict__ parts, int ntiles, int nv,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, size_t zP, size_t zO) {
+    parts += (size_t)blockIdx.z * zP;                        // blockIdx.z: matrix of a batch
+    out += (size_t)blockIdx.z * zO;
     __shared__ double red[256];
     const int m = blockIdx.x;
     double s = 0.0;

@@ -684,11 +684,13 @@ __global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restri
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void small_gemm128_kernel(const double* __restrict__ Abase, int lda, size_t sA,
                                                             const double* __restrict__ Bbase, int ldb, size_t sB,
-                                                            double* __restrict__ Cbase, int ldc, size_t sC, double alpha) {
+                                                            double* __restrict__ Cbase, int ldc, size_t sC, double alpha,
+                                                            size_t zA, size_t zB, size_t zC) {
+    // blockIdx.y: pair of diagonal blocks (strides sA, sB, sC); blockIdx.z: matrix of a batch (strides zA, zB, zC)
     __shared__ double As[32][33], Bs[32][33];
-    const double* A = Abase + (size_t)blockIdx.y * sA;
-    const double* B = Bbase + (size_t)blockIdx.y * sB;
-    double* C = Cbase + (size_t)blockIdx.y * sC;
+    const double* A = Abase + (size_t)blockIdx.y * sA + (size_t)blockIdx.z * zA;
+    const double* B = Bbase + (size_t)blockIdx.y * sB + (size_t)blockIdx.z * zB;
+    double* C = Cbase + (size_t)blockIdx.y * sC + (size_t)blockIdx.z * zC;
     const int r0 = (blockIdx.x & 3) * 32, c0 = (blockIdx.x >> 2) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // ty 0..7 → 4 columns each
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -713,10 +715,10 @@ __global__ __launch_bounds__(256) void small_gemm128_kernel(const double* __rest
 
 // Dinv2_p (256×256, column-major): diagonal quadrants = Dinv128 of blocks 2p, 2p+1; upper right = 0.
 __global__ __launch_bounds__(256) void dinv_pair_assemble_kernel(const double* __restrict__ Dinv128,
-                                                                 double* __restrict__ Dinv2) {
-    const int p = blockIdx.y, c = blockIdx.x;                     // column c of the 256×256 block
-    const double* src = Dinv128 + (size_t)(2 * p + (c >> 7)) * BLK * BLK + (size_t)(c & 127) * BLK;
-    double* dst = Dinv2 + (size_t)p * 4 * BLK * BLK + (size_t)c * 2 * BLK;
+                                                                 double* __restrict__ Dinv2, size_t z128, size_t z2) {
+    const int p = blockIdx.y, c = blockIdx.x;                     // column c of the 256×256 block; blockIdx.z: matrix of a batch
+    const double* src = Dinv128 + (size_t)blockIdx.z * z128 + (size_t)(2 * p + (c >> 7)) * BLK * BLK + (size_t)(c & 127) * BLK;
+    double* dst = Dinv2 + (size_t)blockIdx.z * z2 + (size_t)p * 4 * BLK * BLK + (size_t)c * 2 * BLK;
     const int r = threadIdx.x;                                    // 0..255
     if (c < BLK) {
         if (r < BLK) dst[r] = src[r];                             // lower-left quadrant is written by the GEMM
