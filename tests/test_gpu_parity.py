@@ -1538,3 +1538,14 @@ def test_batched_likelihood_gradients(api, O, d, N, S):
     _, gr1 = g.loglike_grad()
     assert np.allclose(grad[:, 0], gr1, rtol=0, atol=1e-10 * (1 + np.abs(gr1).max()))
     g.close()
+
+
+def test_bo_loop_example_runs():
+    """examples/bo_loop.py: the whole loop (SampleOptMAP-style fit, gradient multistart acquisition maximisation, objective
+    evaluation, dataset augmentation, a sequential batch) on the device — the best feasible value never gets worse."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bo_loop", os.path.join(ROOT, "examples", "bo_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    problem = mod.main(iters=5, seed=1)
+    assert problem.data.X.shape[1] == 8 + 5
