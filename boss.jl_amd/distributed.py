@@ -13,6 +13,9 @@ import numpy as np
 
 
 def _dist():
+    import sys
+    if "torch" not in sys.modules:      # a process that never imported torch cannot have initialised torch.distributed
+        return None                     # (and single-process users do not pay the one-second import)
     try:
         import torch.distributed as dist
         return dist if dist.is_available() and dist.is_initialized() else None
