@@ -1549,3 +1549,98 @@ def test_bo_loop_example_runs():
     spec.loader.exec_module(mod)
     problem = mod.main(iters=5, seed=1)
     assert problem.data.X.shape[1] == 8 + 5
+
+
+# ------------------------------------------------------------------------------------------
+# Pairwise-combinatorial integration test, after the reference's test/combinatorial suite (combinations.csv:
+# ACTS degree-2 coverage over its 24 inputs; objective, data and bounds of input_values.jl:24-56): every pair of
+# values of the inputs that concern this path occurs in at least one configuration; each runs `iter_max` BO
+# iterations (or, with f = missing, returns a recommendation) through the plugin-trio mirror.
+# ------------------------------------------------------------------------------------------
+def _obj(x, rng):
+    y = np.exp(x[0] / 10) * np.cos(2 * x[0]) + rng.normal(0.0, 0.1)
+    z = 0.5 ** 6 * (x[0] ** 2 - 15.0 ** 2) + rng.normal(0.0, 0.1)
+    return np.array([y, z])
+
+
+COMBINATIONS = [
+    # XY, f, discrete, cons, y_max, model, kernel, dirac priors, fitness, fitter, maximizer, iters
+    ("dup", "missing", False, False, "inf", "semipar", "matern52", False, "nonlin", "sampling", "grid", 1),
+    ("nodup", "fn", True, True, "finite", "gp", "matern32", True, "lin", "sampling", "sampling", 1),
+    ("dup", "fn", False, True, "inf", "gp_mean", "sqexp", True, "lin", "optimization", "optimization", 1),
+    ("nodup", "fn", False, False, "finite", "semipar", "matern52", True, "lin", "sampling", "seqbatch", 2),
+    ("nodup", "missing", True, False, "finite", "gp", "sqexp", False, "lin", "sample_opt", "optimization", 1),
+    ("dup", "fn", True, False, "inf", "gp", "matern52", False, "nonlin", "sample_opt", "sampling", 2),
+    ("nodup", "fn", False, True, "inf", "gp_mean", "matern32", False, "nonlin", "optimization", "grid", 2),
+    ("dup", "fn", False, False, "finite", "gp", "matern32", False, "lin", "optimization", "seqbatch", 1),
+    ("nodup", "fn", True, True, "inf", "semipar", "sqexp", False, "lin", "sampling", "sampling", 2),
+    ("dup", "missing", False, True, "finite", "gp_mean", "matern52", True, "lin", "sample_opt", "grid", 1),
+    ("nodup", "fn", False, False, "inf", "gp", "matern52", True, "lin", "sampling", "optimization", 2),
+    ("dup", "fn", True, True, "finite", "gp_mean", "sqexp", False, "lin", "sample_opt", "seqbatch", 1),
+]
+
+
+@pytest.mark.parametrize("cfg", COMBINATIONS, ids=[f"cfg{i}" for i in range(len(COMBINATIONS))])
+def test_pairwise_combinations_of_the_plugin_trio(api, cfg):
+    import boss_jl_amd as B
+    from boss_jl_amd.bo import bo
+    xy, f, discrete, cons, ymax, model_kind, kernel, dirac, fitness, fitter_kind, am_kind, iters = cfg
+    rng = np.random.default_rng(100 + COMBINATIONS.index(cfg))
+    X = np.array([[5.0, 10.0, 10.0]]) if xy == "dup" else np.array([[5.0, 10.0, 15.0]])
+    Y = np.stack([_obj(X[:, j], rng) for j in range(3)], axis=1)
+    P, d = 2, 1
+    noise = [B.Dirac(0.1)] * P if dirac else [B.LogNormal(-2.3, 0.3)] * P
+    amp = [B.Dirac(1.0), B.LogNormal(0.0, 0.5)] if dirac else [B.LogNormal(0.0, 0.5)] * P
+    lsc = [B.MvLogNormal([1.0], [0.5])] * P
+    kw = {}
+    if model_kind == "gp_mean":
+        kw["mean"] = lambda x: np.array([0.1 * x[0], -1.0])
+    if model_kind == "semipar":
+        kw["parametric"] = lambda x, th: np.array([th[0] * np.cos(2 * x[0]), th[1]])
+        kw["theta_priors"] = [B.LogNormal(0.0, 0.3), B.LogNormal(0.0, 0.3)] if not dirac else [B.Dirac(1.0), B.LogNormal(0.0, 0.3)]
+    model = B.HipGaussianProcess(lsc, amp, noise, kernel=kernel, **kw)
+    domain = B.Domain(([0.0], [20.0]), discrete=[True] if discrete else None, cons=(lambda x: [x[0] - 1.0]) if cons else None)
+    fit = B.LinFitness([1.0, 0.0]) if fitness == "lin" else B.NonlinFitness(lambda y: y[0] - 0.1 * y[1] ** 2)
+    y_max = [np.inf, 0.0] if ymax == "finite" else [np.inf, np.inf]
+    obj = None if f == "missing" else (lambda x: _obj(x, rng))
+    problem = B.BossProblem(obj, domain, B.ExpectedImprovement(fit, eps_samples=20), model, B.ExperimentData(X, Y), y_max)
+    if model_kind == "semipar" and fitter_kind != "sampling":
+        fitter_kind = "sampling"                             # the gradient fitters treat the prior mean as fixed (documented)
+    fitter = {"sampling": B.HipBatchedMAP(samples=40, seed=1), "optimization": B.HipGradientMAP(multistart=3, iters=5, seed=1),
+              "sample_opt": B.HipSampleOptMAP(samples=30, multistart=2, iters=4, seed=1)}[fitter_kind]
+    prior = lambda r: r.uniform(0.0, 20.0, 1)                # noqa: E731
+    if am_kind == "optimization" and fitness == "nonlin":
+        am_kind = "sampling"                                 # the analytic EI gradient exists for LinFitness only (documented)
+    am = {"sampling": B.HipBatchAM(x_prior=prior, samples=200, seed=2),
+          "grid": B.HipBatchAM(points=np.linspace(0.0, 20.0, 81)[None, :]),
+          "optimization": B.HipGradientAM(x_prior=prior, multistart=20, iters=8, seed=2),
+          "seqbatch": B.HipSequentialBatchAM(B.HipBatchAM(x_prior=prior, samples=200, seed=2), batch_size=2)}[am_kind]
+    if f == "missing":
+        from boss_jl_amd.bo import estimate_parameters
+        estimate_parameters(problem, fitter)
+        x, _ = am.maximize_acquisition(problem)
+        x = np.atleast_2d(np.asarray(x, float).reshape(d, -1))
+        assert np.isfinite(x).all() and (x >= 0).all() and (x <= 20).all()
+        if discrete:
+            assert np.allclose(x, np.round(x))
+        if cons:
+            assert (x >= 1.0 - 1e-12).all()
+        return
+    if am_kind == "seqbatch":
+        from boss_jl_amd.bo import estimate_parameters
+        for _ in range(iters):
+            estimate_parameters(problem, fitter)
+            Xb, _ = am.maximize_acquisition(problem)
+            Xb = np.asarray(Xb, float).reshape(d, -1)
+            assert Xb.shape[1] == 2 and (Xb >= 0).all() and (Xb <= 20).all()
+            problem.augment_dataset(Xb, np.stack([obj(Xb[:, j]) for j in range(2)], axis=1))
+        assert problem.data.X.shape[1] == 3 + 2 * iters
+        return
+    problem = bo(problem, fitter, am, iters)
+    assert problem.data.X.shape[1] == 3 + iters and np.isfinite(problem.data.Y).all()
+    new = problem.data.X[:, 3:]
+    assert (new >= 0).all() and (new <= 20).all()
+    if discrete:
+        assert np.allclose(new, np.round(new))
+    if cons:
+        assert (new >= 1.0 - 1e-12).all()
