@@ -47,8 +47,8 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------
 // pinned host block per device: results of the acquisition epilogue, then two staging areas that let calls with a
 // handful of candidates skip a stream synchronisation (upload) and two of three download copies
-constexpr size_t PINNED_BYTES = 64 * 1024, PINNED_UP_OFF = 4096, PINNED_UP_BYTES = 32 * 1024, PINNED_DOWN_OFF = 36 * 1024,
-                 PINNED_DOWN_BYTES = 28 * 1024;
+constexpr size_t PINNED_UP_OFF = 4096, PINNED_UP_BYTES = 1024 * 1024, PINNED_DOWN_OFF = PINNED_UP_OFF + PINNED_UP_BYTES,
+                 PINNED_DOWN_BYTES = 512 * 1024, PINNED_BYTES = PINNED_DOWN_OFF + PINNED_DOWN_BYTES;
 
 // every device allocation goes through here; BOSS_POISON_ALLOC=1 (tests) fills new memory with NaN bit patterns so that
 // reads of never-written memory show up instead of passing on the zeros a fresh process happens to get
