@@ -205,6 +205,7 @@ struct boss_gp {
     std::vector<unsigned char> discrete;
     double amp2 = 0.0;
     bool has_mean = false, fitted = false, pending = false, have_dinv = false;
+    bool dinv_used = false;                    // the current block inverses were used by a prediction (see factor_enqueue)
     double* host_res = nullptr;                // pinned: scal[2], info
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued

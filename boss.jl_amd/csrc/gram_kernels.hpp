@@ -24,8 +24,10 @@ __global__ void scale_points_kernel(const double* __restrict__ Xraw, double* __r
 // row for boss_gp_append (the z entries of the columns before it are final and must survive).
 __global__ void rhs_rows_kernel(double* __restrict__ Abase, int ld, size_t bstride, int N, int Np,
                                 const double* __restrict__ y, const double* __restrict__ mean, size_t mean_bstride,
-                                int col0) {
+                                int col0, int* __restrict__ info) {
+    // info (or null): the failed-pivot flag of matrix b, cleared here so that an update needs no separate memset
     const int b = blockIdx.z;
+    if (info && blockIdx.x == 0 && threadIdx.x == 0) info[b] = 0;
     const int j = col0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Np) return;
     double* col = Abase + (size_t)b * bstride + (size_t)j * ld + Np;
