@@ -439,20 +439,21 @@ __global__ __launch_bounds__(256, 2) void potrf_rowupd_kernel(double* __restrict
 }
 
 // logdet = 2 Σ_{i<N} log L_ii ,  zz = Σ_{j<N} z_j²   →  scal[2*b], scal[2*b+1]
-__global__ __launch_bounds__(256) void potrf_logdet_kernel(const double* __restrict__ Abase, int ld, size_t bstride,
-                                                           int N, int Np, double* __restrict__ scal) {
+constexpr int LOGDET_THREADS = 1024;                          // at the end of the chain: every thread takes N/1024 diagonal entries
+__global__ __launch_bounds__(LOGDET_THREADS) void potrf_logdet_kernel(const double* __restrict__ Abase, int ld, size_t bstride,
+                                                                      int N, int Np, double* __restrict__ scal) {
     const double* A = Abase + (size_t)blockIdx.z * bstride;
     double s0 = 0.0, s1 = 0.0;
-    for (int i = threadIdx.x; i < N; i += 256) {
+    for (int i = threadIdx.x; i < N; i += LOGDET_THREADS) {
         s0 += log(A[(size_t)i * ld + i]);
         double z = A[(size_t)i * ld + Np];
         s1 += z * z;
     }
-    __shared__ double r0[256], r1[256];
+    __shared__ double r0[LOGDET_THREADS], r1[LOGDET_THREADS];
     r0[threadIdx.x] = s0;
     r1[threadIdx.x] = s1;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = LOGDET_THREADS / 2; st > 0; st >>= 1) {
         if (threadIdx.x < st) {
             r0[threadIdx.x] += r0[threadIdx.x + st];
             r1[threadIdx.x] += r1[threadIdx.x + st];
