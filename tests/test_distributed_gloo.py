@@ -143,6 +143,48 @@ def _shard_modes(B, D, MX, O, rank, world):
     both = D.allgather_concat(np.concatenate([xg, [vg]]))
     assert np.array_equal(both[:d + 1], both[d + 1:]), both          # same answer on both ranks
     assert abs(O.ei_acquisition([post1], xg[:, None], [1.0], None, bb)[0] - vg) <= 1e-12
+    # ---- fitters: hyper-parameter samples / multistart starts sharded across ranks, identical winner everywhere
+    Xf = rng.uniform(0, 1, (d, 25))
+    Yf = np.stack([np.sin(3 * Xf).sum(0), np.cos(2 * Xf).sum(0)])
+    fmodel = B.HipGaussianProcess(lengthscale_priors=[B.MvLogNormal([-0.7] * d, [0.5] * d)] * 2,
+                                  amplitude_priors=[B.LogNormal(0.0, 0.5)] * 2, noise_std_priors=[B.Dirac(0.05)] * 2)
+    fprob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness([1.0, 0.0])), fmodel,
+                          B.ExperimentData(Xf, Yf))
+    seen = {"batch": [], "grad": []}
+
+    def fake_data_loglike_batch(self, data, samples):
+        seen["batch"].append(len(samples))
+        return np.array([O.data_loglike(data.X, data.Y, "matern52", p.lengthscales, p.amplitudes, p.noise_std) for p in samples])
+
+    def fake_objective_batch(self, model, prior_ll, data, plist):
+        seen["grad"].append(len(plist))
+        S, (dd, P) = len(plist), plist[0].lengthscales.shape
+        tot, gl, ga, gs = np.zeros(S), np.zeros((S, dd, P)), np.zeros((S, P)), np.zeros((S, P))
+        for k, p in enumerate(plist):
+            tot[k] = prior_ll(p)
+            for i in range(P):
+                ll, gr = O.gp_data_loglike_grad(data.X, data.Y[i], "matern52", p.lengthscales[:, i], p.amplitudes[i], p.noise_std[i])
+                tot[k] += ll
+                gl[k, :, i] = gr[:dd] + np.atleast_1d(model.lengthscale_priors[i].grad_logpdf(p.lengthscales[:, i]))
+                ga[k, i] = gr[dd] + model.amplitude_priors[i].grad_logpdf(p.amplitudes[i])
+                gs[k, i] = gr[dd + 1] + model.noise_std_priors[i].grad_logpdf(p.noise_std[i])
+        return tot, gl, ga, gs
+
+    B.HipGaussianProcess.data_loglike_batch = fake_data_loglike_batch
+    B.HipGradientMAP._objective_batch = fake_objective_batch
+    best = B.HipBatchedMAP(samples=11, seed=4).estimate_parameters(fprob)
+    assert sum(seen["batch"]) == len(range(*D.shard_range(11, rank, world)))          # only this rank's shard was evaluated
+    allp = B.HipBatchedMAP(samples=11, seed=4).estimate_parameters(fprob, return_all=True)
+    assert len(allp) == 11 and best.loglike == max(r.loglike for r in allp)
+    fit = B.HipGradientMAP(multistart=5, iters=6, seed=4).estimate_parameters(fprob)
+    lo_, hi_ = D.shard_range(5, rank, world)
+    assert seen["grad"][0] == hi_ - lo_                                                # first round: this rank's starts
+    flat = np.concatenate([fit.params.lengthscales.reshape(-1), fit.params.amplitudes, fit.params.noise_std, [fit.loglike]])
+    both = D.allgather_concat(flat)
+    assert np.array_equal(both[:flat.size], both[flat.size:])                          # same winner on both ranks
+    assert fit.loglike >= best.loglike - 1e-9 and np.all(fit.params.noise_std == 0.05)
+    so = B.HipSampleOptMAP(samples=11, multistart=3, iters=4, seed=4).estimate_parameters(fprob)
+    assert so.loglike >= best.loglike - 1e-9
     # ---- raw collectives
     tot = D.allreduce_sum(np.arange(4.0) + rank)
     assert np.array_equal(tot, world * np.arange(4.0) + sum(range(world)))
