@@ -55,6 +55,7 @@ constexpr size_t PINNED_UP_OFF = 4096, PINNED_UP_BYTES = 1024 * 1024, PINNED_DOW
 static hipError_t dev_malloc(void** p, size_t bytes) {
     static const bool poison = getenv("BOSS_POISON_ALLOC") && atoi(getenv("BOSS_POISON_ALLOC"));
     hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();            // a failed allocation must not surface later as a stale launch error
     if (e == hipSuccess && poison) {
         (void)hipMemset(*p, 0xff, bytes);                    // null stream: the library's streams do not wait for it ...
         (void)hipDeviceSynchronize();                        // ... so finish it before anything else touches the block
