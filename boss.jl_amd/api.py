@@ -44,6 +44,7 @@ SIGNATURES = {
     "boss_gp_set_y": (C.c_int, [C.c_void_p, _c_dp]),
     "boss_gp_loglike_grad": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
     "boss_gp_reserve": (C.c_int, [C.c_void_p, C.c_int]),
+    "boss_gp_n": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "boss_gp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_gp_free": (None, [C.c_void_p]),
     "boss_gp_get_factor": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
@@ -234,8 +235,9 @@ class GP:
             raise ValueError("mean_new must have one entry per new point")
         out = C.c_double(0.0)
         rc = load_library().boss_gp_append(self._h, n, _dp(X_new), _dp(y_new), _dp(m), C.byref(out))
-        if rc in (BOSS_OK, BOSS_E_NOT_PD):
-            self.N += n                      # the data were appended even if the factorisation failed
+        cnt = C.c_int(self.N)                # the device's own count: observations stay appended when the factorisation
+        load_library().boss_gp_n(self._h, C.byref(cnt))   # fails, and a failed multi-append may have taken only some
+        self.N = cnt.value
         _check(rc)
         self.logpdf = out.value
         return out.value

@@ -94,27 +94,25 @@ struct Ctx {
 static std::mutex g_ctx_mtx;
 static std::map<int, Ctx*> g_ctx;
 
-static int get_ctx(int device, Ctx** out) {
-    std::lock_guard<std::mutex> lk(g_ctx_mtx);
-    auto it = g_ctx.find(device);
-    if (it != g_ctx.end()) {
-        *out = it->second;
-        HIPCHK(hipSetDevice(device));
-        return BOSS_OK;
+static void ctx_destroy(Ctx* c) {
+    if (!c) return;
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+    for (int i = 0; i < Ctx::LLG_BANKS - 1; ++i) {
+        if (c->llg_stream[i]) (void)hipStreamDestroy(c->llg_stream[i]);
+        if (c->llg_join[i]) (void)hipEventDestroy(c->llg_join[i]);
     }
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BOSS_E_NO_DEVICE, "no HIP device visible (bosship has no CPU fallback)");
-    if (device < 0 || device >= n) return fail(BOSS_E_INVALID, "device index out of range");
-    HIPCHK(hipSetDevice(device));
-    Ctx* c = new Ctx();
-    c->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    delete c;
+}
+
+static int ctx_init(Ctx* c) {
     {
         // Panel chain on the highest-priority stream, bulk trailing updates on the lowest-priority one.
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        (void)hipStreamDestroy(c->own_stream);
         HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest));
         c->stream = c->own_stream;
         HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
@@ -149,6 +147,28 @@ static int get_ctx(int device, Ctx** out) {
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG64>::BYTES));
+    return BOSS_OK;
+}
+
+static int get_ctx(int device, Ctx** out) {
+    std::lock_guard<std::mutex> lk(g_ctx_mtx);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) {
+        *out = it->second;
+        HIPCHK(hipSetDevice(device));
+        return BOSS_OK;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BOSS_E_NO_DEVICE, "no HIP device visible (bosship has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(BOSS_E_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    Ctx* c = new Ctx();
+    c->device = device;
+    int rc = ctx_init(c);
+    if (rc) {                                                // a half-built context does not stay behind
+        ctx_destroy(c);
+        return rc;
+    }
     g_ctx[device] = c;
     *out = c;
     return BOSS_OK;
@@ -275,6 +295,8 @@ extern "C" int boss_set_stream(int device, void* hip_stream) {
     Ctx* c;
     int rc = get_ctx(device, &c);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    HIPCHK(hipStreamSynchronize(c->stream));                // nothing enqueued on the old stream may still be in flight
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return BOSS_OK;
 }

@@ -46,20 +46,80 @@ def _device_for(d, group):
     return torch.device("cpu")
 
 
+_BUF = {}
+
+
+def _buffers(d, group, dev, world, n):
+    """Per-(group, device, length) exchange buffers, allocated once: the arg-max exchange runs once per
+    acquisition pass and must not allocate device tensors every time."""
+    key = (id(group), str(dev), world, n)
+    b = _BUF.get(key)
+    if b is None:
+        import torch
+        b = (torch.empty(n, dtype=torch.float64, device=dev), torch.empty(world * n, dtype=torch.float64, device=dev))
+        _BUF[key] = b
+    return b
+
+
 def argmax_exchange(val: float, idx: int, group=None) -> Tuple[float, int]:
     """Global arg-max of per-rank (value, GLOBAL index) pairs: larger value wins, NaN counts as
-    the largest (Julia argmax), ties go to the smaller index — identical on every rank."""
+    the largest (Julia argmax), ties go to the smaller index — identical on every rank.
+    One 16-byte all-gather (all_gather_into_tensor on preallocated buffers), one device->host copy."""
     d = _dist()
     if d is None or d.get_world_size(group) == 1:
         return val, idx
     import torch
     dev = _device_for(d, group)
     world = d.get_world_size(group)
-    mine = torch.tensor([val, float(idx)], dtype=torch.float64, device=dev)
-    out = [torch.empty(2, dtype=torch.float64, device=dev) for _ in range(world)]
-    d.all_gather(out, mine, group=group)
-    pairs = [(float(t[0]), int(t[1])) for t in out]
+    mine, out = _buffers(d, group, dev, world, 2)
+    mine.copy_(torch.tensor([val, float(idx)], dtype=torch.float64))
+    d.all_gather_into_tensor(out, mine, group=group)
+    flat = out.cpu().tolist()
+    pairs = [(flat[2 * r], int(flat[2 * r + 1])) for r in range(world)]
     return reduce_pairs(pairs)
+
+
+def shared_seed(seed, group=None) -> int:
+    """The seed every rank must use so that all ranks draw the SAME candidates / prior samples (the exchanged global
+    index is applied to local arrays).  An explicit seed is returned as is; with seed=None rank 0 draws one and
+    broadcasts it (8 bytes) — independent default_rng(None) streams on the ranks would silently return different
+    points on different ranks."""
+    if seed is not None:
+        return int(seed)
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return int(np.random.SeedSequence().entropy % (1 << 63))
+    import torch
+    dev = _device_for(d, group)
+    t = torch.zeros(1, dtype=torch.int64, device=dev)
+    if d.get_rank(group) == 0:
+        t[0] = int(np.random.SeedSequence().entropy % (1 << 62))
+    d.broadcast(t, src=d.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.cpu()[0])
+
+
+def broadcast_array(local, shape, src: int, group=None) -> np.ndarray:
+    """float64 array of known `shape` from group rank `src` to every rank (one fixed-size broadcast)."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return np.asarray(local, dtype=np.float64).reshape(shape)
+    import torch
+    dev = _device_for(d, group)
+    if d.get_rank(group) == src:
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64).reshape(shape).copy()).to(dev)
+    else:
+        t = torch.empty(tuple(shape), dtype=torch.float64, device=dev)
+    d.broadcast(t, src=d.get_global_rank(group, src) if group is not None else src, group=group)
+    return t.cpu().numpy()
+
+
+def owner_of_index(i: int, n: int, world: int) -> int:
+    """The rank whose shard_range(n, rank, world) contains item i."""
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        if lo <= i < hi:
+            return r
+    raise IndexError(i)
 
 
 def reduce_pairs(pairs):
@@ -78,13 +138,29 @@ def reduce_pairs(pairs):
 
 
 def allgather_concat(local: np.ndarray, group=None) -> np.ndarray:
-    """Concatenate per-rank 1-D float64 arrays (ragged shards allowed)."""
+    """Concatenate per-rank 1-D float64 arrays (ragged shards allowed): one all-gather of the lengths, one
+    fixed-size all-gather of the (padded) payloads — tensors only, nothing is pickled."""
     d = _dist()
+    local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1)
     if d is None or d.get_world_size(group) == 1:
-        return np.asarray(local, dtype=np.float64)
-    objs = [None] * d.get_world_size(group)
-    d.all_gather_object(objs, np.asarray(local, dtype=np.float64), group=group)
-    return np.concatenate(objs)
+        return local
+    import torch
+    dev = _device_for(d, group)
+    world = d.get_world_size(group)
+    n_mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    n_all = torch.empty(world, dtype=torch.int64, device=dev)
+    d.all_gather_into_tensor(n_all, n_mine, group=group)
+    counts = [int(v) for v in n_all.cpu().tolist()]
+    nmax = max(counts)
+    if nmax == 0:
+        return np.zeros(0)
+    pad = np.zeros(nmax)
+    pad[:local.shape[0]] = local
+    mine = torch.from_numpy(pad).to(dev)
+    out = torch.empty(world * nmax, dtype=torch.float64, device=dev)
+    d.all_gather_into_tensor(out, mine, group=group)
+    a = out.cpu().numpy()
+    return np.concatenate([a[r * nmax:r * nmax + counts[r]] for r in range(world)])
 
 
 def allreduce_sum(local: np.ndarray, group=None) -> np.ndarray:

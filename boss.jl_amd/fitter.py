@@ -37,7 +37,7 @@ class HipBatchedMAP:
     def estimate_parameters(self, problem: BossProblem, options: BossOptions = BossOptions(), return_all: bool = False):
         """estimate_parameters(::SamplingMAP, problem, options; return_all) (sampling.jl:17-28)."""
         model: HipGaussianProcess = problem.model
-        rng = np.random.default_rng(self.seed)
+        rng = np.random.default_rng(dist_util.shared_seed(self.seed, self.group))     # the same draws on every rank
         sampler = model.params_sampler()
         prior_ll = model.params_loglike()
         draws: List[HipGPParams] = [sampler(rng) for _ in range(self.samples)]     # same stream on every rank
@@ -104,7 +104,7 @@ class HipGradientMAP:
         if model.parametric is not None:
             raise NotImplementedError("HipGradientMAP treats the prior mean as fixed; use HipBatchedMAP for Semiparametric models")
         data = problem.data
-        rng = np.random.default_rng(self.seed)
+        rng = np.random.default_rng(dist_util.shared_seed(self.seed, self.group))     # the same starts on every rank
         sampler, prior_ll = model.params_sampler(), model.params_loglike()
         if self.starts is not None:
             starts: List[HipGPParams] = list(self.starts)
@@ -165,10 +165,9 @@ class HipGradientMAP:
         if world == 1:
             return MAPParams(best[1], best_v)
         mine = best[1] if best and best[0] == gi else None
-        flat = np.zeros(0) if mine is None else np.concatenate([mine.lengthscales.reshape(-1, order="F"), mine.amplitudes,
-                                                                mine.noise_std])
-        flat = dist_util.allgather_concat(flat, self.group)
+        flat = None if mine is None else np.concatenate([mine.lengthscales.reshape(-1, order="F"), mine.amplitudes, mine.noise_std])
         d = data.X.shape[0]
+        flat = dist_util.broadcast_array(flat, (d * P + 2 * P,), dist_util.owner_of_index(gi, nstart, world), self.group)
         return MAPParams(HipGPParams(flat[:d * P].reshape(d, P, order="F"), flat[d * P:d * P + P], flat[d * P + P:]), best_v)
 
 

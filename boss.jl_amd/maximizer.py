@@ -130,7 +130,7 @@ class HipBatchAM:
     def candidates(self, problem: BossProblem) -> np.ndarray:
         if self.points is not None:
             return np.asfortranarray(self.points, dtype=np.float64)
-        rng = np.random.default_rng(self.seed)
+        rng = np.random.default_rng(dist_util.shared_seed(self.seed, self.group))     # the same draws on every rank
         xs = [_rand_in_domain(self.x_prior, problem.domain, rng, self.max_attempts) for _ in range(self.samples)]
         xs = [x for x in xs if x is not None]                          # _reduce_samples (sampling.jl:77-79)
         if not xs:
@@ -258,10 +258,11 @@ class HipSequentialBatchAM:
                     am, mx = M, -np.inf
                 mx, am = dist_util.argmax_exchange(mx, am, self.am.group)
                 x = Xs[:, am].copy()
-                yl = np.zeros(0)
+                yl = None
                 if lo <= am < hi:                                        # the owner reads ŷ = mean(post, x) off its tracks
                     yl = sum(np.array([t.moments(am - lo, 1)[0][0] for t in ts]) for ts in tracks) / len(tracks)
-                y = dist_util.allgather_concat(yl, self.am.group) if world > 1 else yl
+                P = prob.data.Y.shape[0]                                 # one fixed-size broadcast from the owner
+                y = dist_util.broadcast_array(yl, (P,), dist_util.owner_of_index(am, M, world), self.am.group) if world > 1 else yl
                 prob.augment_dataset(x, y)
                 for p in posts:
                     p.append(x, y)
@@ -315,7 +316,7 @@ class HipGradientAM:
         return acc / len(posts), gacc / len(posts)
 
     def maximize_acquisition(self, problem: BossProblem, options: BossOptions = BossOptions(), posts=None):
-        rng = np.random.default_rng(self.seed)
+        rng = np.random.default_rng(dist_util.shared_seed(self.seed, self.group))     # the same starts on every rank
         dom = problem.domain
         starts = [_rand_in_domain(self.x_prior, dom, rng, self.max_attempts) for _ in range(self.multistart)]
         starts = [x for x in starts if x is not None]
@@ -351,8 +352,8 @@ class HipGradientAM:
             j = int(np.argmax(fm))
             best_v, best_i, Xf = float(fm[j]), lo + j, X
         best_v, gi = dist_util.argmax_exchange(best_v, best_i, self.group)
-        if world > 1:
-            cols = dist_util.allgather_concat(Xf.reshape(-1, order="F") if Xf is not None else np.zeros(0), self.group)
-            Xall = cols.reshape(X0.shape[0], -1, order="F")
-            return Xall[:, gi].copy(), best_v
+        if world > 1:                                        # the winner's refined point: one d-double broadcast from its owner
+            owner = dist_util.owner_of_index(gi, X0.shape[1], world)
+            mine = Xf[:, gi - lo] if owner == rank else None
+            return dist_util.broadcast_array(mine, (X0.shape[0],), owner, self.group), best_v
         return Xf[:, gi - lo].copy(), best_v

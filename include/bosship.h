@@ -98,13 +98,17 @@ int boss_gp_set_y(boss_gp_t* gp, const double* y);
  * (n entries, or NULL for zero).  Only the 128-row blocks that contain new observations are
  * rebuilt (O(N^2) work per block instead of the O(N^3) re-factorisation); the result — factor,
  * z = L^{-1}(y-m), logpdf of all N+n observations — equals a fresh fit of the augmented data
- * to rounding.  The handle must be fitted; device storage grows as needed.
+ * to rounding.  The handle must be fitted; device storage grows as needed.  A posterior that was updated with a
+ * prior mean (mean_X) requires mean_new (BOSS_E_INVALID otherwise).
  * From the second single-observation append after an update (the pattern of SequentialBatchAM and of
  * a BO loop that keeps its hyper-parameters) the handle keeps both inverse factors resident and an
  * append is one pass over each of them (rank-one append: L <- [L 0; l' d], L^-1 <- [L^-1 0; -w'/d 1/d]);
  * BOSS_WINV_AFTER=0 in the environment keeps every append on the block path. */
 int boss_gp_append(boss_gp_t* gp, int n, const double* X_new, const double* y_new, const double* mean_new,
                    double* logpdf_out);
+/* number of observations currently in the handle (after a boss_gp_append that failed part-way — n in 2..8 single
+ * appends on resident inverse factors — it tells how many of them were taken). */
+int boss_gp_n(const boss_gp_t* gp, int* n_out);
 /* Reserve device storage for N_total observations (appends up to that size then need no
  * re-allocation).  Leaves the handle unfitted: follow with boss_gp_update. */
 int boss_gp_reserve(boss_gp_t* gp, int N_total);

@@ -66,7 +66,10 @@ def build(name, kernel, d, N, M, noise, amp, with_mean, discrete, seed):
         "noise_std": noise, "mean_X": None if mX is None else mX.tolist(), "mean_Xs": None if ms is None else ms.tolist(),
         "discrete": discrete, "logpdf": post.logpdf, "mu": mu.tolist(), "var": var.tolist(),
         "z": O.sla.solve_triangular(post.L, post.delta, lower=True).tolist(),
-        "L_diag": np.diag(post.L).tolist(), "best": best, "acq_ei": acq.tolist(), "argmax": int(np.argmax(acq)),
+        "L_diag": np.diag(post.L).tolist(),
+        # full factor, lower triangle packed column by column (kept to the cases where it stays small)
+        "L_packed": None if N > 130 else np.concatenate([post.L[j:, j] for j in range(N)]).tolist(),
+        "best": best, "acq_ei": acq.tolist(), "argmax": int(np.argmax(acq)),
     }
 
 

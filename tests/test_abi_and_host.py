@@ -77,6 +77,17 @@ def test_product_path_never_imports_oracle():
         assert "oracle" not in open(os.path.join(pkg, "csrc", fn)).read()
 
 
+def test_shipped_library_has_no_work_skipping_switches():
+    """BOSS_DBG (skip GEMM1 / GEMM2 / K* / the V store in the prediction kernel) and BOSS_EXP_NOREST (drop trailing
+    updates) are timing experiments: they exist only in -DBOSS_EXPERIMENTS builds.  The shipped library must not even
+    contain their names (a bench number must not be one environment variable away from skipping its FLOPs)."""
+    from boss_jl_amd import api
+    blob = open(api.LIB_PATH, "rb").read()
+    for name in (b"BOSS_DBG", b"BOSS_EXP_NOREST"):
+        assert name not in blob, name
+    assert "BOSS_EXPERIMENTS" not in " ".join(entry.HIPCC_FLAGS)
+
+
 def test_golden_fixtures_match_oracle():
     from oracle import gp_oracle as O
     cases = json.load(open(os.path.join(ROOT, "tests", "golden", "gp_golden.json")))

@@ -102,6 +102,11 @@ def _shard_modes(B, D, MX, O, rank, world):
         j = int(np.argmax(a))
         return a, j, float(a[j])
 
+    def fake_acq_nomask(problem, posts, Xc, cand=None):
+        a = O.ei_acquisition(posts, Xc, coefs, y_max, b)
+        j = int(np.argmax(a))
+        return a, j, float(a[j])
+
     def fake_output_moments(problem, i, Xc):
         calls["moments"].append(i)
         return np.stack([np.stack(O.gp_mean_and_var(all_posts[s][i], Xc)) for s in range(S)])
@@ -130,6 +135,21 @@ def _shard_modes(B, D, MX, O, rank, world):
     assert np.array_equal(x, Xs[:, j]) and abs(val - full[j]) <= 1e-15 * (1 + abs(full[j]))
     _, allv = am.maximize_acquisition(prob, return_all=True)
     assert np.allclose(allv, full, rtol=0, atol=1e-15)
+    # ---- unseeded maximiser: rank 0's seed is broadcast, so every rank draws the same candidates and returns the same point
+    MX.posteriors_of, MX.acquisition_values = fake_posteriors_of, fake_acq_nomask
+    for _ in range(2):
+        amu = B.HipBatchAM(x_prior=lambda r: r.uniform(0, 1, d), samples=23)          # seed=None
+        xu, vu = amu.maximize_acquisition(prob)
+        both = D.allgather_concat(np.concatenate([xu, [vu]]))
+        assert np.array_equal(both[:d + 1], both[d + 1:]), both
+        assert abs(O.ei_acquisition(all_posts, xu[:, None], coefs, y_max, b)[0] - vu) <= 1e-12
+    s1, s2 = D.shared_seed(None), D.shared_seed(None)
+    assert s1 != s2 and D.shared_seed(17) == 17
+    both = D.allgather_concat(np.array([float(s1 % 2 ** 40), float(s2 % 2 ** 40)]))
+    assert np.array_equal(both[:2], both[2:])
+    assert np.array_equal(D.broadcast_array(np.arange(3.0) + rank if rank == 1 else None, (3,), 1), np.arange(3.0) + 1)
+    assert [D.owner_of_index(i, 5, 2) for i in range(5)] == [0, 0, 0, 1, 1]
+    MX.posteriors_of, MX.acquisition_values = fake_posteriors_of, fake_acq
     # ---- gradient multistart: starts sharded across ranks, identical winner on every rank
     post1 = O.gp_fit(X, Y[0], "matern52", [0.4, 0.5], 1.0, 0.05)
     bb = float(Y[0].max())
@@ -185,6 +205,16 @@ def _shard_modes(B, D, MX, O, rank, world):
     assert fit.loglike >= best.loglike - 1e-9 and np.all(fit.params.noise_std == 0.05)
     so = B.HipSampleOptMAP(samples=11, multistart=3, iters=4, seed=4).estimate_parameters(fprob)
     assert so.loglike >= best.loglike - 1e-9
+    # unseeded fitters: the broadcast seed makes every rank draw the same samples / starts and return the same winner
+    for fitter in (B.HipBatchedMAP(samples=9), B.HipGradientMAP(multistart=4, iters=3), B.HipSampleOptMAP(samples=9, multistart=2, iters=3)):
+        r = fitter.estimate_parameters(fprob)
+        flat = np.concatenate([r.params.lengthscales.reshape(-1), r.params.amplitudes, r.params.noise_std, [r.loglike]])
+        both = D.allgather_concat(flat)
+        assert np.array_equal(both[:flat.size], both[flat.size:]), type(fitter).__name__
+    allu = B.HipBatchedMAP(samples=9).estimate_parameters(fprob, return_all=True)
+    chk = np.array([O.data_loglike(fprob.data.X, fprob.data.Y, "matern52", q.params.lengthscales, q.params.amplitudes, q.params.noise_std)
+                    + fmodel.params_loglike()(q.params) for q in allu])
+    assert np.allclose(chk, [q.loglike for q in allu], rtol=0, atol=1e-9)        # draws paired with THEIR values on every rank
     # ---- raw collectives
     tot = D.allreduce_sum(np.arange(4.0) + rank)
     assert np.array_equal(tot, world * np.arange(4.0) + sum(range(world)))

@@ -90,28 +90,76 @@ def test_condition_aware_tolerance_sweep(api, O, noise):
     g.close()
 
 
-def test_golden_fixtures(api):
+def test_golden_fixtures(api, O):
+    """The committed fixtures at the stated 1e-9 bar (condition-aware beyond cond(K) = 1e6), the whole factor
+    included: packed in the fixture for N <= 130, against the oracle on the fixture's inputs above that."""
     cases = json.load(open(os.path.join(ROOT, "tests", "golden", "gp_golden.json")))
     for c in cases:
         X, y, Xs = np.array(c["X"]), np.array(c["y"]), np.array(c["Xs"])
+        N = X.shape[1]
+        post = O.gp_fit(X, y, c["kernel"], c["lengthscale"], c["amplitude"], c["noise_std"], mean=c["mean_X"], discrete=c["discrete"])
+        tol, _ = tol_for(O, post, N)                       # 1e-9 unless the fixture is stiff (ref_fixture_3pt: σ = 1e-4)
         g = api.fit(X, y, c["kernel"], c["lengthscale"], c["amplitude"], c["noise_std"], c["mean_X"], c["discrete"])
-        assert abs(g.logpdf - c["logpdf"]) <= 1e-9 * (1 + abs(c["logpdf"])), c["name"]
+        assert abs(g.logpdf - c["logpdf"]) <= tol * (1 + abs(c["logpdf"])), c["name"]
         L, z = g.factor()
+        if c["L_packed"] is not None:
+            Lg = np.zeros((N, N))
+            pk, o = np.array(c["L_packed"]), 0
+            for j in range(N):
+                Lg[j:, j] = pk[o:o + N - j]
+                o += N - j
+        else:
+            Lg = post.L
+        assert np.array_equal(np.triu(L, 1), np.zeros((N, N))), c["name"]
+        assert np.allclose(L, Lg, rtol=0, atol=tol * np.abs(Lg).max()), c["name"]
         assert np.allclose(np.diag(L), c["L_diag"], rtol=1e-10, atol=0), c["name"]
-        assert np.allclose(z, c["z"], rtol=0, atol=1e-8 * (1 + np.abs(c["z"]).max())), c["name"]
+        assert np.allclose(z, c["z"], rtol=0, atol=tol * (1 + np.abs(c["z"]).max())), c["name"]
         try:
             mu, var = g.predict(Xs, c["mean_Xs"])
         except api.DomainError:
             assert min(c["var"]) < -1e-8
             continue
-        assert np.allclose(mu, c["mu"], rtol=0, atol=1e-8 * (1 + np.abs(c["mu"]).max())), c["name"]
-        assert np.allclose(var, np.maximum(c["var"], 0.0), rtol=0, atol=1e-8 * c["amplitude"] ** 2), c["name"]
+        assert np.allclose(mu, c["mu"], rtol=0, atol=tol * (1 + np.abs(c["mu"]).max())), c["name"]
+        assert np.allclose(var, np.maximum(c["var"], 0.0), rtol=0, atol=tol * c["amplitude"] ** 2), c["name"]
         cand = api.Candidates(Xs)
         ms = None if c["mean_Xs"] is None else np.array(c["mean_Xs"])[None, None, :]
         acq, am, mx = api.acq_ei([[g]], cand, [1.0], [np.inf], c["best"], None, ms)
-        assert np.allclose(acq, c["acq_ei"], rtol=0, atol=1e-8), c["name"]
+        assert np.allclose(acq, c["acq_ei"], rtol=0, atol=tol), c["name"]
         assert am == c["argmax"] or abs(acq[am] - c["acq_ei"][c["argmax"]]) <= 1e-12, c["name"]
         g.close()
+
+
+def test_gemm_form_distances_on_the_reference_fixture(api, O):
+    """KernelFunctions evaluates pairwise distances through Distances.jl's ‖a‖²+‖b‖²−2a·b; the HIP
+    kernels take direct differences.  On the reference's own stiff fixture (X = [2 5 8; 2 5 8], noise Dirac(1e-4),
+    test/unit/test/models/gaussian_process.jl:57-73) and on a bench-shaped problem the device results stay inside the
+    condition-aware bound of the oracle evaluated in the GEMM form."""
+    X3 = np.array([[2., 5., 8.], [2., 5., 8.]])
+    Xs = np.array([[1., 2., 3., 4., 5.5, 100.], [1., 2., 3., 4., 5.5, 100.]])
+    ms = np.ones(Xs.shape[1])
+    for kernel in ("matern52", "matern32", "sqexp"):
+        for lam in ([2.5, 3.5], [1.0, 1.0], [6.0, 9.0], [40.0, 60.0], [200.0, 300.0]):   # cond(K) from 1 to 7e7
+            pg = O.gp_fit(X3, X3[0], kernel, lam, 1.3, 1e-4, mean=1.0, form="gemm")
+            mu_g, var_g = O.gp_mean_and_var(pg, Xs, ms, clip=False, form="gemm")
+            tol, cond = tol_for(O, pg, 3)
+            # the two distance forms differ by O(eps ‖x/λ‖²) in r², amplified by cond(K) in the posterior
+            scale = max(1.0, float(np.max(np.sum((X3 / np.array(lam)[:, None]) ** 2, axis=0))))
+            tol = max(tol, cond * 2.0 ** -53 * 16 * scale)
+            g = api.fit(X3, X3[0], kernel, lam, 1.3, 1e-4, np.ones(3))
+            assert abs(g.logpdf - pg.logpdf) <= tol * (1 + abs(pg.logpdf)), (kernel, lam)
+            mu, var = g.predict(Xs, ms)
+            assert np.allclose(mu, mu_g, rtol=0, atol=tol * (1 + np.abs(mu_g).max())), (kernel, lam, cond)
+            assert np.allclose(var, np.where(var_g >= 0, var_g, 0.0), rtol=0, atol=tol * 1.3 ** 2), (kernel, lam, cond)
+            g.close()
+    X, y, Xc = make(8, 512, 64, seed=5)
+    lam = np.full(8, 0.5)
+    pg = O.gp_fit(X, y, "matern52", lam, 1.0, 0.05, form="gemm")
+    mu_g, var_g = O.gp_mean_and_var(pg, Xc, clip=False, form="gemm")
+    g = api.fit(X, y, "matern52", lam, 1.0, 0.05)
+    mu, var = g.predict(Xc)
+    assert abs(g.logpdf - pg.logpdf) <= 1e-9 * (1 + abs(pg.logpdf))
+    assert np.allclose(mu, mu_g, rtol=0, atol=1e-9 * (1 + np.abs(mu_g).max())) and np.allclose(var, var_g, rtol=0, atol=1e-9)
+    g.close()
 
 
 def test_semiparametric_mean_and_discrete(api, O):
@@ -330,6 +378,122 @@ def test_full_size_properties(api, O):
     # (5) interpolation property: predicting AT the data recovers y to within the noise level
     mu, var = g.predict(X[:, :256])
     assert np.abs(mu - y[:256]).max() < 0.2 and np.all(var >= 0) and np.all(var < 0.05 ** 2 + 1e-6)
+    g.close()
+
+
+def test_config4_semiparametric_two_constrained_outputs_full_size(api, O):
+    """BASELINE.json configs[3]: Semiparametric model (affine parametric mean + GP), 2 outputs constrained by
+    y_max = [Inf, 0.5], N = 2048, d = 6, 8192 candidates (src/models/semiparametric.jl:79-92 for the posterior and
+    likelihood, src/acquisitions/expected_improvement.jl:68-90 for EI x feasibility) — through the C ABI, through the
+    plugin mirror, and with the outputs sharded (`shard="outputs"`, world size 1)."""
+    import boss_jl_amd as B
+    rng = np.random.default_rng(3)
+    d, N, M, P = 6, 2048, 8192, 2
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), np.cos(2 * X).sum(0) - 1.0]) + 0.05 * rng.standard_normal((P, N))
+    Xs = np.asfortranarray(rng.uniform(0, 1, (d, M)))
+    th = np.array([0.1, 0.2, -0.3])
+    w = np.linspace(0.5, 1.5, d)
+    para = lambda x, t: np.array([t[0] + t[1] * float(w @ x), t[0] + t[2] * float(w @ x)])    # m(x; θ) = θ₁ + θ₂ᵀx per output
+    mX = np.stack([th[0] + th[1] * (w @ X), th[0] + th[2] * (w @ X)])
+    mS = np.stack([th[0] + th[1] * (w @ Xs), th[0] + th[2] * (w @ Xs)])
+    lam = np.stack([np.full(d, 0.5), np.linspace(0.4, 0.7, d)], axis=1)
+    amp, sig = np.array([1.0, 0.8]), np.array([0.05, 0.07])
+    coefs, y_max = [1.0, 0.0], np.array([np.inf, 0.5])
+    b = O.best_so_far(coefs, Y, y_max)
+    assert b is not None
+    posts = [O.gp_fit(X, Y[p], "matern52", lam[:, p], amp[p], sig[p], mean=mX[p]) for p in range(P)]
+    # (1) posterior construction and likelihood (semiparametric.jl:86-92 = Σ_p logpdf with the parametric mean)
+    gps = [api.GP(X, Y[p], "matern52") for p in range(P)]
+    lps = [gps[p].update(lam[:, p], amp[p], sig[p], mean_X=mX[p]) for p in range(P)]
+    for p in range(P):
+        assert abs(lps[p] - posts[p].logpdf) <= 1e-9 * (1 + abs(posts[p].logpdf))
+    # (2) EI x feasibility over all 8192 candidates: a 512-candidate slice against the oracle, whole-batch arg-max
+    #     consistent, and the slice-only call equal to the slice of the batch
+    cand = api.Candidates(Xs)
+    acq, am, mx = api.acq_ei([gps], cand, coefs, y_max, b, None, mS[None])
+    assert am == int(np.argmax(acq)) and mx == acq[am] and np.all(acq >= 0) and np.isfinite(acq).all()
+    sl = slice(3000, 3512)
+    want = O.ei_acquisition(posts, Xs[:, sl], coefs, y_max, b, means_s=[mS[0, sl], mS[1, sl]])
+    assert np.allclose(acq[sl], want, rtol=0, atol=1e-10)
+    acq_sl, _, _ = api.acq_ei([gps], api.Candidates(Xs[:, sl]), coefs, y_max, b, None, mS[None, :, sl])
+    assert np.allclose(acq_sl, acq[sl], rtol=0, atol=1e-13)
+    # moments of both outputs on a slice
+    for p in range(P):
+        mu, var = gps[p].predict(Xs[:, sl], mS[p, sl])
+        mu_o, var_o = O.gp_mean_and_var(posts[p], Xs[:, sl], mS[p, sl])
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9 * (1 + np.abs(mu_o).max())) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+    # the constraint matters: the unconstrained acquisition differs, and feasibility only ever lowers it
+    acq_u, _, _ = api.acq_ei([gps], cand, coefs, None, b, None, mS[None])
+    assert np.all(acq <= acq_u + 1e-15) and np.any(acq < 0.9 * acq_u)
+    for g in gps:
+        g.close()
+    # (3) the same through the plugin mirror (Semiparametric = HipGaussianProcess(parametric=...)), candidates and
+    #     outputs sharding modes; the two agree with each other and with (2)
+    model = B.HipGaussianProcess([None] * P, [None] * P, [None] * P, parametric=para, theta_priors=[None] * 3)
+    prm = B.HipGPParams(lam, amp, sig, th)
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness(coefs)), model,
+                         B.ExperimentData(X, Y), y_max, prm)
+    ll = model.data_loglike(prob.data)
+    assert abs(ll(prm) - sum(q.logpdf for q in posts)) <= 1e-9 * (1 + abs(sum(q.logpdf for q in posts)))
+    for h in ll.handles:
+        h.close()
+    res = {}
+    for mode in ("candidates", "outputs"):
+        amx = B.HipBatchAM(points=Xs, shard=mode)
+        x, val = amx.maximize_acquisition(prob)
+        _, allv = amx.maximize_acquisition(prob, return_all=True)
+        res[mode] = (x, val, allv)
+        assert np.allclose(allv, acq, rtol=0, atol=1e-12), mode
+        assert np.array_equal(x, Xs[:, am]) and abs(val - mx) <= 1e-12, mode
+
+
+def test_config5_bi_512_samples_full_size(api, O):
+    """BASELINE.json configs[4]: TuringBI-style fit — S = 512 posterior hyper-parameter samples, each with its own
+    N = 1024 Cholesky (ext/TuringExt.jl:88-107 draws them; every one is a data_loglike evaluation,
+    gaussian_process.jl:250-280), then the acquisition averaged over the S resident posteriors
+    (src/posterior.jl:15-19, expected_improvement.jl:87-90)."""
+    d, N, S, M = 8, 1024, 512, 256
+    X, y, Xs = make(d, N, M, seed=4)
+    rng = np.random.default_rng(4)
+    lam = np.exp(-0.7 + 0.3 * rng.standard_normal((d, S)))
+    amp = np.exp(0.3 * rng.standard_normal(S))
+    sig = np.exp(-3 + 0.3 * rng.standard_normal(S))
+    ll, st = api.loglike_batch(X, y, "matern52", lam, amp, sig)
+    assert np.all(st == api.BOSS_OK) and np.isfinite(ll).all()
+    # (1) 40 of the 512 sets against the oracle (first, last, and a spread in between)
+    idx = sorted(set([0, 1, 7, S - 1] + list(range(3, S, 14))))
+    assert len(idx) >= 32
+    for s in idx:
+        want = O.gp_data_loglike_slice(X, y, "matern52", lam[:, s], amp[s], sig[s])
+        assert abs(ll[s] - want) <= 1e-9 * (1 + abs(want)), s
+    # (2) every member of the batch equals the single-handle update of the same set (the batched schedule is a
+    #     different code path: paired panels, one stream) on a further 24 sets
+    g = api.GP(X, y, "matern52")
+    for s in range(5, S, 22):
+        one = g.update(lam[:, s], amp[s], sig[s])
+        assert abs(one - ll[s]) <= 1e-11 * (1 + abs(one)), s
+    # (3) ordering property (test/unit/test/models/gaussian_process.jl:261-316): with everything else fixed the
+    #     likelihood prefers the generating noise level to a grossly wrong one — on all 512 sets at once
+    ll_bad, st_bad = api.loglike_batch(X, y, "matern52", lam, amp, np.full(S, 5.0))
+    assert np.all(st_bad == api.BOSS_OK) and np.all(ll > ll_bad)
+    # (4) a permutation of the sets permutes the results (no cross-talk between batch members)
+    perm = np.random.default_rng(0).permutation(S)
+    ll_p, _ = api.loglike_batch(X, y, "matern52", lam[:, perm], amp[perm], sig[perm])
+    assert np.array_equal(ll_p, ll[perm])
+    # (5) BI-averaged acquisition over resident posteriors: 16 of the samples stay resident, EI is the mean over them
+    sub = list(range(0, S, 32))
+    gps = [[api.fit(X, y, "matern52", lam[:, s], amp[s], sig[s])] for s in sub]
+    posts = [[O.gp_fit(X, y, "matern52", lam[:, s], amp[s], sig[s])] for s in sub]
+    b = float(y.max())
+    acq, am, mx = api.acq_ei(gps, api.Candidates(Xs), [1.0], [np.inf], b)
+    want = O.ei_acquisition(posts, Xs, [1.0], [np.inf], b)
+    assert np.allclose(acq, want, rtol=0, atol=1e-10) and am == int(np.argmax(acq)) and mx == acq[am]
+    # average_mean (src/posterior.jl:177-179) of the resident posteriors
+    mus = np.mean([gp[0].predict(Xs)[0] for gp in gps], axis=0)
+    assert np.allclose(mus, O.average_mean(posts, Xs)[0], rtol=0, atol=1e-9 * (1 + np.abs(mus).max()))
+    for gp in gps:
+        gp[0].close()
     g.close()
 
 
@@ -575,6 +739,16 @@ def test_append_zero_mean_discrete_and_errors(api, O):
     assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9)
     with pytest.raises(ValueError):
         g.append(np.zeros((3, 1)), [0.0])
+    # a posterior with a prior mean needs the mean at the new points (it must not silently become 0 there)
+    gm = api.GP(X[:, :N0], y[:N0], "matern32", disc)
+    gm.update([1.5, 2.0], 1.0, 0.1, mean_X=0.3 * X[0, :N0])
+    with pytest.raises(api.BossError) as e:
+        gm.append(X[:, N0], y[N0])
+    assert e.value.code == api.BOSS_E_INVALID and gm.N == N0
+    lpm = gm.append(X[:, N0], y[N0], [0.3 * X[0, N0]])
+    want = O.gp_fit(X[:, :N0 + 1], y[:N0 + 1], "matern32", [1.5, 2.0], 1.0, 0.1, mean=0.3 * X[0, :N0 + 1], discrete=disc).logpdf
+    assert abs(lpm - want) <= 1e-10 * (1 + abs(want)) and gm.N == N0 + 1
+    gm.close()
     # a duplicated point with (almost) no noise makes the augmented matrix singular -> PosDefException
     X2 = rng.uniform(0, 6, (d, N0))
     g2 = api.GP(X2, np.cos(X2).sum(0), "matern32")
