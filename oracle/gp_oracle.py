@@ -153,6 +153,41 @@ def kernelmatrix(h: GPHyper, Xa: np.ndarray, Xb: Optional[np.ndarray] = None,
     return (h.amplitude ** 2) * kappa(h.kernel, r)
 
 
+def kernelmatrix_blas(h: GPHyper, X: np.ndarray) -> np.ndarray:
+    """kernelmatrix(k, X) the way the reference's stack evaluates it (src/models/utils/kernels.jl:35 prints the
+    metric: Distances.Euclidean): pairwise distances as ‖a‖²+‖b‖²−2a·b with the cross term from ONE BLAS-3 call
+    (dgemm, multithreaded), then the radial profile broadcast over the N×N matrix — in place, so that a timing of it
+    measures arithmetic and not temporaries.  Same values as kernelmatrix(..., form="gemm") up to the order of the
+    three additions.  Used by bench.py's cpu_baseline leg."""
+    Xa = discrete_round(np.asarray(X, dtype=np.float64), h.discrete)
+    A = Xa * (1.0 / h.lengthscale)[:, None]
+    sa = np.einsum("ij,ij->j", A, A)
+    R = A.T @ A                                   # dgemm
+    R *= -2.0
+    R += sa[:, None]
+    R += sa[None, :]
+    np.maximum(R, 0.0, out=R)
+    amp2 = h.amplitude ** 2
+    if h.kernel == SQEXP:
+        R *= -0.5
+        np.exp(R, out=R)
+        R *= amp2
+        return R
+    np.sqrt(R, out=R)
+    R *= _SQRT3 if h.kernel == MATERN32 else _SQRT5       # s
+    E = np.exp(-R)
+    if h.kernel == MATERN32:
+        R += 1.0                                          # 1 + s
+    else:
+        T = R * R
+        T *= 1.0 / 3.0
+        R += T
+        R += 1.0                                          # 1 + s + s²/3
+    R *= E
+    R *= amp2
+    return R
+
+
 # --------------------------------------------------------------------------------------
 # posterior construction   (gaussian_process.jl:199-211 -> AbstractGPs.posterior(fx, y))
 # --------------------------------------------------------------------------------------
@@ -184,7 +219,7 @@ def _mean_vec(mean, X: np.ndarray) -> np.ndarray:
 
 
 def gp_fit(X, y, kernel, lengthscale, amplitude, noise_std, mean=None, discrete=None,
-           form: str = "direct") -> GPPosterior:
+           form: str = "direct", timings: Optional[dict] = None) -> GPPosterior:
     """posterior_gp (gaussian_process.jl:199-211): K = kernelmatrix + σ²I; C = cholesky(K);
     δ = y - m(X); a = C \\ δ.  logpdf(FiniteGP, y) = -(N log 2π + logdet C + ||C.U' \\ δ||²)/2
     (gaussian_process.jl:279; algebra spelled out in gradient_gp.jl:325-326,403)."""
@@ -192,18 +227,26 @@ def gp_fit(X, y, kernel, lengthscale, amplitude, noise_std, mean=None, discrete=
     y = np.asarray(y, dtype=np.float64).reshape(-1)
     d, N = X.shape
     assert y.shape[0] == N
+    import time
+    t0 = time.perf_counter()
     h = finite_gp_params(kernel, d, lengthscale, amplitude, noise_std, discrete)
-    K = kernelmatrix(h, X, form=form)
+    K = kernelmatrix_blas(h, X) if form == "blas" else kernelmatrix(h, X, form=form)
     K[np.diag_indices(N)] += h.noise_std ** 2
+    t1 = time.perf_counter()
     try:
-        L = sla.cholesky(K, lower=True, check_finite=False)
+        L = sla.cholesky(K, lower=True, check_finite=False, overwrite_a=timings is not None)
     except np.linalg.LinAlgError as e:  # PosDefException in Julia
         raise PosDefException(str(e))
+    t2 = time.perf_counter()
     delta = y - _mean_vec(mean, X)
     z = sla.solve_triangular(L, delta, lower=True, check_finite=False)
     a = sla.solve_triangular(L, z, lower=True, trans="T", check_finite=False)
     logdet = 2.0 * float(np.sum(np.log(np.diag(L))))
     logpdf = -0.5 * (N * _LOG2PI + logdet + float(z @ z))
+    if timings is not None:                  # bench.py's cpu_baseline leg: where one posterior update spends its time
+        timings["gram"] = timings.get("gram", 0.0) + (t1 - t0)
+        timings["potrf"] = timings.get("potrf", 0.0) + (t2 - t1)
+        timings["trsv_logdet"] = timings.get("trsv_logdet", 0.0) + (time.perf_counter() - t2)
     return GPPosterior(h, X, L, a, delta, logpdf)
 
 
