@@ -99,6 +99,12 @@ def cpu_baseline(X, y, Xs, lam):
     except Exception:
         cores = os.cpu_count()
     cores = min(cores, len(os.sched_getaffinity(0)))
+    try:                                                   # a container's CPU quota (cgroup v2): more BLAS threads than that only thrash
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     from threadpoolctl import threadpool_limits
     with threadpool_limits(limits=cores):
         O.gp_fit(X, y, KERNEL, lam, 1.0, 0.05, form="blas")                # warm-up: first-touch of the big temporaries

@@ -70,6 +70,18 @@ SIGNATURES = {
     "boss_track_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_dp, _c_dp]),
     "boss_acq_ei_tracks": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), _c_dp, _c_dp, C.c_int, C.c_double, _c_ucp,
                                      _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_init": (C.c_int, [C.POINTER(C.c_int)]),
+    "boss_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "boss_shutdown": (None, []),
+    "boss_multi_gp_update": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), _c_dp, C.c_double, C.c_double, _c_dp, _c_dp]),
+    "boss_multi_acq_ei": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
+                                    C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_multi_acq_ei_outputs": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
+                                            C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_multi_acq_ei_samples": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
+                                            C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_multi_loglike_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp, C.c_int,
+                                           _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
     "boss_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _c_dp]),
     "boss_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "boss_prof_reset": (C.c_int, [C.c_int]),
@@ -632,6 +644,125 @@ def acq_ei_moments(mu, var, fit_coefs, y_max=None, best=None, valid_mask=None, d
                                               0 if best is None else 1, 0.0 if best is None else float(best),
                                               _ucp(mask), _dp(acq), C.byref(am), C.byref(mx)))
     return acq, am.value, mx.value
+
+
+# ---------------------------------------------------------------- several GPUs from one process (boss_multi_*)
+def init() -> int:
+    """boss_init: open every visible device and (when RCCL loads) a communicator on each; returns the device count."""
+    n = C.c_int(0)
+    _check(load_library().boss_init(C.byref(n)))
+    return n.value
+
+
+def comm_info():
+    """(devices opened by init(), exchanges over RCCL?)"""
+    n, r = C.c_int(0), C.c_int(0)
+    _check(load_library().boss_comm_info(C.byref(n), C.byref(r)))
+    return n.value, bool(r.value)
+
+
+def shutdown():
+    load_library().boss_shutdown()
+
+
+def multi_update(replicas: Sequence[GP], lengthscale, amplitude, noise_std, mean_X=None) -> float:
+    """The same hyper-parameters on the replicas of one posterior (replicas[g] on device g), factorised concurrently."""
+    G = len(replicas)
+    arr = (C.c_void_p * G)(*[r._h for r in replicas])
+    lam = _f64(np.asarray(lengthscale).reshape(-1), 1)
+    if lam.shape[0] != replicas[0].d:
+        raise BossError(BOSS_E_INVALID, "length(lengthscales) must equal x_dim")
+    m = None if mean_X is None else _f64(np.asarray(mean_X).reshape(-1), 1)
+    out = C.c_double(0.0)
+    _check(load_library().boss_multi_gp_update(G, arr, _dp(lam), float(amplitude), float(noise_std), _dp(m), C.byref(out)))
+    for r in replicas:
+        r.logpdf = out.value
+    return out.value
+
+
+def _acq_common(P, S, M, fit_coefs, y_max, valid_mask, mean_Xs):
+    coefs = _f64(np.asarray(fit_coefs).reshape(-1), 1)
+    ym = None if y_max is None else _f64(np.asarray(y_max).reshape(-1), 1)
+    mask = None if valid_mask is None else np.ascontiguousarray(np.asarray(valid_mask, dtype=bool).astype(np.uint8))
+    ms = None
+    if mean_Xs is not None:
+        a = np.asarray(mean_Xs, dtype=np.float64).reshape(S, P, M)
+        ms = np.ascontiguousarray(a.transpose(0, 2, 1))       # index p + P*(j + M*s)
+    return coefs, ym, mask, ms
+
+
+def multi_acq_ei(replicas: Sequence[Sequence[Sequence[GP]]], Xs, fit_coefs, y_max=None, best=None, valid_mask=None,
+                 mean_Xs=None, want_acq: bool = True):
+    """boss_multi_acq_ei: candidates sharded over the devices.  replicas[g][s][p] = replica on device g of output p,
+    hyper-parameter sample s.  Xs d×M (host); mean_Xs None or [S][P][M].  Returns (acq[M] or None, argmax, max)."""
+    G, S, P = len(replicas), len(replicas[0]), len(replicas[0][0])
+    Xs = _f64(Xs, 2)
+    M = Xs.shape[1]
+    arr = (C.c_void_p * (G * S * P))()
+    for g in range(G):
+        for s in range(S):
+            for p in range(P):
+                arr[p + P * (s + S * g)] = replicas[g][s][p]._h
+    coefs, ym, mask, ms = _acq_common(P, S, M, fit_coefs, y_max, valid_mask, mean_Xs)
+    acq = np.zeros(M) if want_acq else None
+    am, mx = C.c_long(-1), C.c_double(0.0)
+    _check(load_library().boss_multi_acq_ei(G, P, S, arr, M, _dp(Xs), _dp(ms), _dp(coefs), _dp(ym), 0 if best is None else 1,
+                                            0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am), C.byref(mx)))
+    return acq, am.value, mx.value
+
+
+def _multi_handles(fn_name, gps, Xs, fit_coefs, y_max, best, valid_mask, mean_Xs, want_acq):
+    S, P = len(gps), len(gps[0])
+    Xs = _f64(Xs, 2)
+    M = Xs.shape[1]
+    arr = (C.c_void_p * (P * S))()
+    for s in range(S):
+        for p in range(P):
+            arr[p + P * s] = gps[s][p]._h
+    coefs, ym, mask, ms = _acq_common(P, S, M, fit_coefs, y_max, valid_mask, mean_Xs)
+    acq = np.zeros(M) if want_acq else None
+    am, mx = C.c_long(-1), C.c_double(0.0)
+    _check(getattr(load_library(), fn_name)(P, S, arr, M, _dp(Xs), _dp(ms), _dp(coefs), _dp(ym), 0 if best is None else 1,
+                                            0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am), C.byref(mx)))
+    return acq, am.value, mx.value
+
+
+def multi_acq_ei_outputs(gps: Sequence[Sequence[GP]], Xs, fit_coefs, y_max=None, best=None, valid_mask=None, mean_Xs=None,
+                         want_acq: bool = True):
+    """boss_multi_acq_ei_outputs: gps[s][p] may live on any device (outputs sharded one per GPU)."""
+    return _multi_handles("boss_multi_acq_ei_outputs", gps, Xs, fit_coefs, y_max, best, valid_mask, mean_Xs, want_acq)
+
+
+def multi_acq_ei_samples(gps: Sequence[Sequence[GP]], Xs, fit_coefs, y_max=None, best=None, valid_mask=None, mean_Xs=None,
+                         want_acq: bool = True):
+    """boss_multi_acq_ei_samples: all outputs of sample s on one device, different samples on different devices."""
+    return _multi_handles("boss_multi_acq_ei_samples", gps, Xs, fit_coefs, y_max, best, valid_mask, mean_Xs, want_acq)
+
+
+def multi_loglike_batch(G: int, X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=None, discrete=None):
+    """boss_multi_loglike_batch: the S hyper-parameter sets split over devices 0..G-1.  Returns (ll[S], status[S])."""
+    X = _f64(X, 2)
+    y = _f64(np.asarray(y).reshape(-1), 1)
+    lam = _f64(lengthscales, 2)
+    d, N = X.shape
+    S = lam.shape[1]
+    if lam.shape[0] != d:
+        raise BossError(BOSS_E_INVALID, "lengthscales must be d×S")
+    amp = _f64(np.asarray(amplitudes).reshape(-1), 1)
+    sig = _f64(np.asarray(noise_stds).reshape(-1), 1)
+    stride, m = 0, None
+    if mean_X is not None:
+        m = np.asarray(mean_X, dtype=np.float64)
+        if m.ndim == 2:
+            m, stride = np.ascontiguousarray(m), N
+        else:
+            m = np.ascontiguousarray(m.reshape(-1))
+    disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
+    ll = np.zeros(S)
+    st = np.zeros(S, dtype=np.int32)
+    _check(load_library().boss_multi_loglike_batch(G, _kernel_id(kernel), d, N, _dp(X), _dp(y), _dp(m), stride, _ucp(disc), S,
+                                                   _dp(lam), _dp(amp), _dp(sig), _dp(ll), st.ctypes.data_as(C.POINTER(C.c_int))))
+    return ll, st
 
 
 def bench_mfma_f64(device: int = 0, iters: int = 20000) -> float:

@@ -315,6 +315,7 @@ extern "C" int boss_device_sync(int device) {
 #include "host_predict.inc"
 #include "host_acq.inc"
 #include "host_track.inc"
+#include "host_multi.inc"
 
 // ------------------------------------------------------------------------------------------
 // measurement helpers

@@ -12,47 +12,89 @@ check(rc) = rc == 0 ? nothing :
 kernel_id(k) = k isa BOSS.Matern32Kernel ? 0 : k isa BOSS.Matern52Kernel ? 1 : 2      # SqExponential / Gaussian
 
 # ---------------------------------------------------------------- SurrogateModel
-"GaussianProcess whose posterior lives on an MI355X. Wraps a BOSS.GaussianProcess for priors/vectorizer/bijector."
+"GaussianProcess whose posterior lives on an MI355X.  Wraps a BOSS.GaussianProcess for its mean, kernel and priors."
 struct HipGaussianProcess{G<:BOSS.GaussianProcess} <: BOSS.SurrogateModel
     gp::G
     device::Cint
 end
-const HipGPParams = BOSS.GaussianProcessParams         # same (λ, α, σ) container
-for f in (:params_loglike, :_params_sampler, :vectorizer, :bijector)
-    @eval $f(m::HipGaussianProcess, args...) = $f(m.gp, args...)
+HipGaussianProcess(gp::BOSS.GaussianProcess; device = 0) = HipGaussianProcess(gp, Cint(device))
+
+"""
+The parameters of `HipGaussianProcess`.  It MUST be its own type: `update_parameters!` asserts
+`typeof(problem.model) <: M` for `FittedParams{M}` (src/types/problem.jl:177-179), and `MAPParams{M}` takes its `M` from
+`ModelParams{M}` (src/types/parameters.jl:118-123) — an alias of `GaussianProcessParams <: ModelParams{GaussianProcess}`
+would fail that assert under an unmodified `bo!`.
+"""
+struct HipGPParams{L<:AbstractMatrix{<:Real}, A<:AbstractVector{<:Real}, N<:AbstractVector{<:Real}} <: BOSS.ModelParams{HipGaussianProcess}
+    λ::L
+    α::A
+    σ::N
 end
+to_gp(p::HipGPParams) = BOSS.GaussianProcessParams(p.λ, p.α, p.σ)
+to_hip(p::BOSS.GaussianProcessParams) = HipGPParams(p.λ, p.α, p.σ)
+
+# the model API of src/types/surrogate_model.jl:19-73, delegated to the wrapped GaussianProcess with the parameter
+# container converted at the boundary (gaussian_process.jl:85-119, :282-343)
+params_loglike(m::HipGaussianProcess) = (ll = params_loglike(m.gp); (p::HipGPParams) -> ll(to_gp(p)))
+_params_sampler(m::HipGaussianProcess) = (sample = _params_sampler(m.gp); rng -> to_hip(sample(rng)))
+function vectorizer(m::HipGaussianProcess)
+    vec_gp, devec_gp = vectorizer(m.gp)                    # skips Dirac-prior parameters (src/models/utils/dirac.jl:36-77)
+    vectorize(p::HipGPParams) = vec_gp(to_gp(p))
+    devectorize(p::HipGPParams, ps::AbstractVector{<:Real}) = to_hip(devec_gp(to_gp(p), ps))
+    return vectorize, devectorize
+end
+bijector(m::HipGaussianProcess) = bijector(m.gp)           # acts on the vectorised parameters: no container involved
+BOSS.param_priors(m::HipGaussianProcess) = BOSS.param_priors(m.gp)
+BOSS.param_count(p::HipGPParams) = sum(BOSS.param_lengths(p))
+BOSS.param_lengths(p::HipGPParams) = (length(p.λ), length(p.α), length(p.σ))
+BOSS.param_shapes(p::HipGPParams) = (size(p.λ), size(p.α), size(p.σ))
 sliceable(::HipGaussianProcess) = true
 slice(m::HipGaussianProcess, i::Int) = HipGaussianProcess(slice(m.gp, i), m.device)
+slice(p::HipGPParams, i::Int) = HipGPParams(p.λ[:, i:i], p.α[i:i], p.σ[i:i])
+join_slices(ps::AbstractVector{<:HipGPParams}) =
+    HipGPParams(hcat(getfield.(ps, Ref(:λ))...), vcat(getfield.(ps, Ref(:α))...), vcat(getfield.(ps, Ref(:σ))...))
 make_discrete(m::HipGaussianProcess, d::AbstractVector{Bool}) = HipGaussianProcess(make_discrete(m.gp, d), m.device)
 
-mutable struct HipPosteriorSlice <: BOSS.ModelPosteriorSlice{HipGaussianProcess}
-    h::Ptr{Cvoid}; mean                                            # prior mean closure (or nothing)
-    function HipPosteriorSlice(h, mean); p = new(h, mean)
-        finalizer(p -> ccall((:boss_gp_free, lib), Cvoid, (Ptr{Cvoid},), p.h), p); end
+"A device handle owned by Julia: freed by the garbage collector (or `close`)."
+mutable struct Handle
+    h::Ptr{Cvoid}
+    function Handle(h::Ptr{Cvoid})
+        obj = new(h)
+        finalizer(close, obj)
+    end
+end
+Base.close(o::Handle) = (o.h == C_NULL || ccall((:boss_gp_free, lib), Cvoid, (Ptr{Cvoid},), o.h); o.h = C_NULL; nothing)
+Base.unsafe_convert(::Type{Ptr{Cvoid}}, o::Handle) = o.h
+
+struct HipPosteriorSlice <: BOSS.ModelPosteriorSlice{HipGaussianProcess}
+    h::Handle
+    mean                                                           # prior mean of this output: nothing, a Real or x -> Real
 end
 mean_vals(::Nothing, X) = C_NULL
 mean_vals(m::Real, X) = fill(Float64(m), size(X, 2))
 mean_vals(m::Function, X) = Float64[m(x) for x in eachcol(X)]
+has_mean(post::HipPosteriorSlice) = !isnothing(post.mean)
 discrete_flags(k) = k isa BOSS.DiscreteKernel && !(k.dims isa Missing) ? UInt8.(k.dims) : C_NULL
+base_kernel(k) = k isa BOSS.DiscreteKernel ? k.kernel : k
 
 function model_posterior_slice(m::HipGaussianProcess, p::HipGPParams, data::BOSS.ExperimentData, i::Int)
     X = Matrix{Float64}(data.X); y = Vector{Float64}(data.Y[i, :])
-    mu = BOSS.mean_getindex(m.gp.mean, i)
+    mu = BOSS.mean_getindex(m.gp.mean, i)                          # gaussian_process.jl:101-103
     h = Ref{Ptr{Cvoid}}(); lp = Ref{Cdouble}()
     check(ccall((:boss_gp_fit, lib), Cint,
         (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble,
          Ptr{UInt8}, Ref{Ptr{Cvoid}}, Ref{Cdouble}),
-        m.device, kernel_id(m.gp.kernel), size(X, 1), size(X, 2), X, y, mean_vals(mu, X),
+        m.device, kernel_id(base_kernel(m.gp.kernel)), size(X, 1), size(X, 2), X, y, mean_vals(mu, X),
         Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], discrete_flags(m.gp.kernel), h, lp))
-    return HipPosteriorSlice(h[], mu)
+    return HipPosteriorSlice(Handle(h[]), mu)
 end
 
 function mean_and_var(post::HipPosteriorSlice, X::AbstractMatrix{<:Real})
     Xs = Matrix{Float64}(X); M = size(Xs, 2)
     μ = Vector{Float64}(undef, M); σ2 = similar(μ); bad = Ref{Clong}(-1)
-    check(ccall((:boss_gp_predict, lib), Cint,
+    GC.@preserve post check(ccall((:boss_gp_predict, lib), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}),
-        post.h, M, Xs, mean_vals(post.mean, Xs), μ, σ2, bad))
+        post.h.h, M, Xs, mean_vals(post.mean, Xs), μ, σ2, bad))
     return μ, σ2
 end
 mean_and_var(post::HipPosteriorSlice, x::AbstractVector{<:Real}) = first.(mean_and_var(post, hcat(x)))
@@ -61,26 +103,28 @@ var(post::HipPosteriorSlice, x) = mean_and_var(post, x)[2]
 function BOSS.mean_and_cov(post::HipPosteriorSlice, X::AbstractMatrix{<:Real})
     Xs = Matrix{Float64}(X); M = size(Xs, 2)
     μ = Vector{Float64}(undef, M); Σ = Matrix{Float64}(undef, M, M); bad = Ref{Clong}(-1)
-    check(ccall((:boss_gp_predict_cov, lib), Cint,
+    GC.@preserve post check(ccall((:boss_gp_predict_cov, lib), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}),
-        post.h, M, Xs, mean_vals(post.mean, Xs), μ, Σ, bad))
+        post.h.h, M, Xs, mean_vals(post.mean, Xs), μ, Σ, bad))
     return μ, Σ
 end
 BOSS.cov(post::HipPosteriorSlice, X::AbstractMatrix{<:Real}) = BOSS.mean_and_cov(post, X)[2]
 
 function data_loglike(m::HipGaussianProcess, data::BOSS.ExperimentData)
     X = Matrix{Float64}(data.X)
-    hs = map(1:size(data.Y, 1)) do i                                   # one resident handle per output
+    hs = map(1:size(data.Y, 1)) do i                                   # one resident handle per output, freed with the closure
         h = Ref{Ptr{Cvoid}}()
         check(ccall((:boss_gp_create, lib), Cint, (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
-              m.device, kernel_id(m.gp.kernel), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]),
-              discrete_flags(m.gp.kernel), h)); h[]
+              m.device, kernel_id(base_kernel(m.gp.kernel)), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]),
+              discrete_flags(m.gp.kernel), h))
+        Handle(h[])
     end
-    return function ll_data(p::HipGPParams)
+    means = [mean_vals(BOSS.mean_getindex(m.gp.mean, i), X) for i in eachindex(hs)]   # the GP's prior mean has no parameters
+    return function ll_data(p::HipGPParams)                            # the closure keeps `hs` alive; the finalizers free them
         sum(eachindex(hs)) do i
             lp = Ref{Cdouble}()
             check(ccall((:boss_gp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Ref{Cdouble}),
-                  hs[i], Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], mean_vals(BOSS.mean_getindex(m.gp.mean, i), X), 0, lp))
+                  hs[i].h, Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], means[i], 0, lp))
             lp[]
         end
     end                                    # exceptions → -Inf via BOSS.safe_data_loglike, as for any model
@@ -100,7 +144,7 @@ function estimate_parameters(f::HipBatchedMAP, problem::BOSS.BossProblem, option
         check(ccall((:boss_gp_loglike_batch, lib), Cint,
             (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint,
              Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
-            m.device, kernel_id(m.gp.kernel), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]),
+            m.device, kernel_id(base_kernel(m.gp.kernel)), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]),
             mean_vals(BOSS.mean_getindex(m.gp.mean, i), X), 0, discrete_flags(m.gp.kernel), f.samples,
             Matrix{Float64}(λ), Float64[p.α[i] for p in ps], Float64[p.σ[i] for p in ps], lli, st))
         ll .+= lli
@@ -115,28 +159,66 @@ Base.@kwdef struct HipBatchAM <: BOSS.AcquisitionMaximizer
     x_prior
     samples::Int
     max_attempts::Int = 200
+    devices::Int = 1              # > 1: candidates sharded over that many GPUs inside the library (boss_multi_acq_ei, RCCL)
+end
+"Prior means at the candidates in the layout boss_acq_ei wants: index p + P*(j + M*s) = a P×M×S array; C_NULL for zero means."
+function prior_means(posts::AbstractVector, xs::AbstractMatrix{Float64})
+    P = length(posts[1].slices); M = size(xs, 2)
+    any(has_mean, posts[1].slices) || return C_NULL
+    ms = zeros(P, M, length(posts))
+    for (s, post) in enumerate(posts), (p, sl) in enumerate(post.slices)
+        isnothing(sl.mean) || (ms[p, :, s] .= mean_vals(sl.mean, xs))      # gaussian_process.jl:101-103: m_p(x_j)
+    end
+    return ms
 end
 function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions;
-                              posts = BOSS.model_posterior(problem))
+                              posts = BOSS.model_posterior(problem), return_all::Bool = false)
     ei = problem.acquisition::BOSS.ExpectedImprovement{<:BOSS.LinFitness}
     xs = BOSS._reduce_samples([BOSS._rand_in_domain(am.x_prior, problem.domain; am.max_attempts) for _ in 1:am.samples])
-    posts isa AbstractVector || (posts = [posts])
+    size(xs, 2) == 0 && @error "HipBatchAM: No samples were successfully drawn!\nCheck the `x_prior` and the `Domain`."
+    xs = Matrix{Float64}(xs)
+    posts isa AbstractVector || (posts = [posts])                          # BI: a vector of posteriors (src/posterior.jl:15-19)
     P = BOSS.y_dim(problem); S = length(posts); M = size(xs, 2)
-    hs = Ptr{Cvoid}[posts[s].slices[p].h for p in 1:P, s in 1:S]
-    cand = Ref{Ptr{Cvoid}}()
-    check(ccall((:boss_cand_create, lib), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
-          problem.model.device, size(xs, 1), M, Matrix{Float64}(xs), cand))
+    hs = Ptr{Cvoid}[posts[s].slices[p].h.h for p in 1:P, s in 1:S]         # P×S, column-major = gps[p + P*s]
     b = BOSS.best_so_far(problem, ei.fitness)
     mask = UInt8[BOSS.in_bounds(x, problem.domain.bounds) && BOSS.in_cons(x, problem.domain.cons) for x in eachcol(xs)]
-    ymax = Float64[isinf(c) ? Inf : c for c in problem.y_max]
+    ymax = Float64[c for c in problem.y_max]                               # BOSS.Infinity converts to Inf (src/utils/inf.jl)
+    ms = prior_means(posts, xs)
+    acq = return_all ? Vector{Float64}(undef, M) : C_NULL
     am_idx = Ref{Clong}(); mx = Ref{Cdouble}()
-    rc = ccall((:boss_acq_ei, lib), Cint,
-        (Cint, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
-         Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
-        P, S, hs, cand[], C_NULL #= mean_Xs: P×M×S when the GP has a prior mean =#, Float64.(ei.fitness.coefs), ymax,
-        isnothing(b) ? 0 : 1, something(b, 0.0), ei.cons_safe ? mask : C_NULL, C_NULL, am_idx, mx)
-    ccall((:boss_cand_free, lib), Cvoid, (Ptr{Cvoid},), cand[]); check(rc)
+    GC.@preserve posts begin
+        if am.devices > 1
+            # replicas of every posterior on devices 1..G-1 under the same hyper-parameters, then ONE sharded call
+            rc = multi_acq_ei(am.devices, problem, posts, xs, ms, ei, ymax, b, mask, acq, am_idx, mx)
+        else
+            cand = Ref{Ptr{Cvoid}}()
+            check(ccall((:boss_cand_create, lib), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+                  problem.model.device, size(xs, 1), M, xs, cand))
+            rc = ccall((:boss_acq_ei, lib), Cint,
+                (Cint, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
+                 Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
+                P, S, hs, cand[], ms, Float64.(ei.fitness.coefs), ymax,
+                isnothing(b) ? 0 : 1, something(b, 0.0), ei.cons_safe ? mask : C_NULL, acq, am_idx, mx)
+            ccall((:boss_cand_free, lib), Cvoid, (Ptr{Cvoid},), cand[])
+        end
+    end
+    check(rc)
+    return_all && return xs, acq
     return xs[:, am_idx[] + 1], mx[]
+end
+"Candidates sharded over G GPUs from this one process (SURVEY §8e): boss_init, replicas via model_posterior_slice on every device."
+function multi_acq_ei(G::Int, problem, posts, xs, ms, ei, ymax, b, mask, acq, am_idx, mx)
+    n = Ref{Cint}(); check(ccall((:boss_init, lib), Cint, (Ref{Cint},), n)); @assert G <= n[]
+    P = BOSS.y_dim(problem); S = length(posts); M = size(xs, 2)
+    params = BOSS.get_params(problem.params); params isa AbstractVector || (params = [params])
+    reps = [g == 0 ? posts : [BOSS.model_posterior(HipGaussianProcess(problem.model.gp, Cint(g)), prm, problem.data) for prm in params]
+            for g in 0:G-1]
+    hs = Ptr{Cvoid}[reps[g][s].slices[p].h.h for p in 1:P, s in 1:S, g in 1:G]      # gps[p + P*(s + S*g)]
+    GC.@preserve reps ccall((:boss_multi_acq_ei, lib), Cint,
+        (Cint, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
+         Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
+        G, P, S, hs, M, xs, ms, Float64.(ei.fitness.coefs), ymax, isnothing(b) ? 0 : 1, something(b, 0.0),
+        ei.cons_safe ? mask : C_NULL, acq, am_idx, mx)
 end
 # ---------------------------------------------------------------- SequentialBatchAM on resident posteriors
 # batch.jl:26-38 rebuilds the posterior (an O(N^3) Cholesky) for every speculative point; here the
@@ -144,7 +226,7 @@ end
 function append!(post::HipPosteriorSlice, x::AbstractVector{<:Real}, y::Real)
     lp = Ref{Cdouble}(); X = reshape(Vector{Float64}(x), :, 1)
     check(ccall((:boss_gp_append, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
-          post.h, 1, X, Float64[y], mean_vals(post.mean, X), lp))
+          post.h.h, 1, X, Float64[y], mean_vals(post.mean, X), lp))    # mean_new is required when the posterior has a prior mean
     return lp[]
 end
 Base.@kwdef struct HipSequentialBatchAM <: BOSS.AcquisitionMaximizer
@@ -167,15 +249,25 @@ end
 function acq_value_and_grad(problem::BOSS.BossProblem, post, X::AbstractMatrix{<:Real})
     ei = problem.acquisition::BOSS.ExpectedImprovement{<:BOSS.LinFitness}
     P = BOSS.y_dim(problem); Xs = Matrix{Float64}(X); d, M = size(Xs)
-    hs = Ptr{Cvoid}[post.slices[p].h for p in 1:P]
+    hs = Ptr{Cvoid}[post.slices[p].h.h for p in 1:P]
     b = BOSS.best_so_far(problem, ei.fitness)
     mask = UInt8[BOSS.in_bounds(x, problem.domain.bounds) && BOSS.in_cons(x, problem.domain.cons) for x in eachcol(Xs)]
+    # prior means [p][M] (an M×P matrix) and their gradients [p][d×M] (a d×M×P array); constant means have zero gradient,
+    # function means are differentiated with ForwardDiff (a BOSS dependency) — only the MEAN, not the GP, goes through duals
+    ms, mg = C_NULL, C_NULL
+    if any(has_mean, post.slices)
+        ms = zeros(M, P); mg = zeros(d, M, P)
+        for (p, sl) in enumerate(post.slices)
+            isnothing(sl.mean) && continue
+            ms[:, p] .= mean_vals(sl.mean, Xs)
+            sl.mean isa Function && (mg[:, :, p] .= reduce(hcat, (BOSS.ForwardDiff.gradient(sl.mean, Vector(x)) for x in eachcol(Xs))))
+        end
+    end
     acq = Vector{Float64}(undef, M); dacq = Matrix{Float64}(undef, d, M)
-    check(ccall((:boss_acq_ei_grad, lib), Cint,
+    GC.@preserve post check(ccall((:boss_acq_ei_grad, lib), Cint,
         (Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble,
          Ptr{UInt8}, Ptr{Cdouble}, Ptr{Cdouble}),
-        P, hs, M, Xs, C_NULL #= [p][M] prior means =#, C_NULL #= [p][d×M] prior-mean gradients =#,
-        Float64.(ei.fitness.coefs), Float64[isinf(c) ? Inf : c for c in problem.y_max], isnothing(b) ? 0 : 1,
+        P, hs, M, Xs, ms, mg, Float64.(ei.fitness.coefs), Float64[c for c in problem.y_max], isnothing(b) ? 0 : 1,
         something(b, 0.0), ei.cons_safe ? mask : C_NULL, acq, dacq))
     return acq, dacq          # feed an Optimization.jl OptimizationFunction(f; grad = ...) per start, or batch the starts
 end
@@ -197,7 +289,7 @@ function loglike_and_grad_batch(m::HipGaussianProcess, data::BOSS.ExperimentData
     check(ccall((:boss_gp_loglike_grad_batch, lib), Cint,
         (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
          Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
-        m.device, kernel_id(m.gp.kernel), d, N, X, Vector{Float64}(data.Y[i, :]), mean_vals(mu, X), 0,
+        m.device, kernel_id(base_kernel(m.gp.kernel)), d, N, X, Vector{Float64}(data.Y[i, :]), mean_vals(mu, X), 0,
         discrete_flags(m.gp.kernel), S, λ, α, σ, ll, g, st))
     return ll, g, st          # ll[s] = -Inf and g[:, s] = 0 where st[s] != 0 (not PD / invalid parameters)
 end
@@ -224,11 +316,11 @@ ggp_update(h, p::BOSS.GradientGaussianProcessParams, i::Int) = (lp = Ref{Cdouble
           h, Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], p.σ_∂[i], 0, lp)); lp[])
 function model_posterior_slice(m::HipGradientGaussianProcess, p::BOSS.GradientGaussianProcessParams, data::BOSS.GradientData, i::Int)
     h = ggp_create(m, data, i); ggp_update(h, p, i)
-    return HipPosteriorSlice(h, nothing)          # mean / var / mean_and_var above apply (gradient_gp.jl:334-361)
+    return HipPosteriorSlice(Handle(h), nothing)  # mean / var / mean_and_var above apply (gradient_gp.jl:334-361)
 end
 function data_loglike(m::HipGradientGaussianProcess, data::BOSS.GradientData)
-    h = ggp_create(m, data, 1)                    # per-output likelihood of the sliced model (gradient_gp.jl:367-397)
-    return p -> try ggp_update(h, p, 1) catch e; e isa PosDefException ? -Inf : rethrow() end
+    h = Handle(ggp_create(m, data, 1))            # per-output likelihood of the sliced model (gradient_gp.jl:367-397)
+    return p -> try ggp_update(h.h, p, 1) catch e; e isa PosDefException ? -Inf : rethrow() end
 end
 # ---------------------------------------------------------------- NonstationaryGP (Gibbs kernel)
 # The latent models stay BOSS's own (ParametrizedGP posteriors or constants); only their values cross the ABI.
@@ -248,14 +340,14 @@ function hip_posterior_slice(model::BOSS.NonstationaryGP, params::BOSS.Nonstatio
           device, size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]), isnothing(model.discrete) ? C_NULL : UInt8.(model.discrete), h))
     check(ccall((:boss_ngp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{Cdouble}),
           h[], reduce(hcat, f_λ.(eachcol(Xr))), Float64.(f_α.(eachcol(Xr))), Float64.(f_σ.(eachcol(X))), mean_vals(mu, X), 0, lp))
-    return HipNonstationaryPosterior(HipPosteriorSlice(h[], mu), f_λ, f_α, model.discrete), lp[]   # lp = data_loglike_slice
+    return HipNonstationaryPosterior(HipPosteriorSlice(Handle(h[]), mu), f_λ, f_α, model.discrete), lp[]   # lp = data_loglike_slice
 end
 function mean_and_var(p::HipNonstationaryPosterior, X::AbstractMatrix{<:Real})
     Xs = Matrix{Float64}(X); Xr = rounded(Xs, p.discrete); M = size(Xs, 2)
     μ = Vector{Float64}(undef, M); σ2 = similar(μ); bad = Ref{Clong}(-1)
     check(ccall((:boss_ngp_predict, lib), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}),
-        p.post.h, M, Xs, reduce(hcat, p.f_λ.(eachcol(Xr))), Float64.(p.f_α.(eachcol(Xr))), mean_vals(p.post.mean, Xs), μ, σ2, bad))
+        p.post.h.h, M, Xs, reduce(hcat, p.f_λ.(eachcol(Xr))), Float64.(p.f_α.(eachcol(Xr))), mean_vals(p.post.mean, Xs), μ, σ2, bad))
     return μ, σ2
 end
 end # module

@@ -126,6 +126,9 @@ class HipBatchAM:
     seed: Optional[int] = None
     group: object = None
     shard: str = "candidates"           # "candidates" | "outputs" | "samples"
+    devices: Optional[Sequence[int]] = None   # ONE process driving GPUs 0..G-1: the shard modes run inside the library
+    #                                           (boss_multi_*: one host thread per device, exchanges over RCCL) — what a Julia
+    #                                           caller uses; None = one process per GPU over torch.distributed (or a single GPU)
 
     def candidates(self, problem: BossProblem) -> np.ndarray:
         if self.points is not None:
@@ -145,6 +148,9 @@ class HipBatchAM:
         Xs = self.candidates(problem)                                   # identical on every rank (seeded)
         M = Xs.shape[1]
         rank, world = dist_util.rank_world(self.group)
+        if self.devices is not None:
+            assert world == 1 and posts is None, "devices=[...] is the single-process mode"
+            return self._maximize_in_library(problem, Xs, return_all)
         if self.shard == "outputs":
             return self._maximize_by_outputs(problem, Xs, rank, world, return_all)
         if self.shard == "samples":
@@ -161,6 +167,53 @@ class HipBatchAM:
         if return_all:
             return Xs, (dist_util.allgather_concat(acq, self.group) if world > 1 else acq)
         mx, am = dist_util.argmax_exchange(mx, am, self.group)
+        return Xs[:, am].copy(), mx
+
+    def _maximize_in_library(self, problem: BossProblem, Xs, return_all):
+        """The three shard modes with ONE process driving the devices: posteriors are created on the devices the mode
+        assigns them to and the library shards / exchanges itself (boss_multi_acq_ei*)."""
+        import dataclasses
+        ei = problem.acquisition
+        if isinstance(ei.fitness, NonlinFitness):
+            raise NotImplementedError("devices=[...] needs the analytic EI of LinFitness")
+        devs = list(self.devices)
+        G = len(devs)
+        if devs != list(range(G)) or api.init() < G:
+            raise ValueError("devices must be [0, ..., G-1] with G <= the number of visible GPUs")
+        P, S, M = problem.data.Y.shape[0], n_samples(problem), Xs.shape[1]
+        plist = list(problem.params) if isinstance(problem.params, (list, tuple)) else [problem.params]
+        on = lambda g: dataclasses.replace(problem.model, device=g)
+        b = best_so_far(ei.fitness, problem.data.Y, problem.y_max)
+        mask = (in_bounds(Xs, problem.domain.bounds) & in_cons(Xs, problem.domain.cons)) if ei.cons_safe else None
+        means = None
+        if problem.model.mean_values(Xs[:, :1], plist[0], 0) is not None:
+            means = np.stack([np.stack([problem.model.mean_values(Xs, prm, i) for i in range(P)]) for prm in plist])   # S×P×M
+        slices = []                                                      # everything to close afterwards
+        try:
+            if self.shard == "candidates":                               # replicas on every device, columns split M/G
+                reps = []
+                for g in range(G):
+                    row = [[on(g).model_posterior_slice(prm, problem.data, i) for i in range(P)] for prm in plist]
+                    slices += [sl for r in row for sl in r]
+                    reps.append([[sl.gp for sl in r] for r in row])
+                acq, am, mx = api.multi_acq_ei(reps, Xs, ei.fitness.coefs, problem.y_max, b, mask, means)
+            elif self.shard == "outputs":                                # output i on device i mod G
+                row = [[on(dist_util.owner_of(i, G)).model_posterior_slice(prm, problem.data, i) for i in range(P)] for prm in plist]
+                slices += [sl for r in row for sl in r]
+                acq, am, mx = api.multi_acq_ei_outputs([[sl.gp for sl in r] for r in row], Xs, ei.fitness.coefs, problem.y_max, b, mask, means)
+            else:                                                        # sample s on the device of its shard
+                assert self.shard == "samples", self.shard
+                row = []
+                for g in range(G):
+                    lo, hi = dist_util.shard_range(S, g, G)
+                    row += [[on(g).model_posterior_slice(prm, problem.data, i) for i in range(P)] for prm in plist[lo:hi]]
+                slices += [sl for r in row for sl in r]
+                acq, am, mx = api.multi_acq_ei_samples([[sl.gp for sl in r] for r in row], Xs, ei.fitness.coefs, problem.y_max, b, mask, means)
+        finally:
+            for sl in slices:
+                sl.close()
+        if return_all:
+            return Xs, acq
         return Xs[:, am].copy(), mx
 
     # (the two modes below factorise only a shard of the outputs / samples on each rank)

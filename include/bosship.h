@@ -301,6 +301,56 @@ int boss_acq_ei_tracks(int P, int S, boss_track_t* const* tracks, const double* 
                        int has_best, double best, const unsigned char* valid_mask,
                        double* acq_out, long* argmax_out, double* max_out);
 
+/* ---- several GPUs from ONE process (north_star: "shard embarrassingly across the 8 GPUs of one node with a
+ * single RCCL allreduce over xGMI for the argmax") ---------------------------------------------------------------
+ * What a Julia caller — no torch, no MPI — uses to spread the acquisition path over the GPUs of a node.  The devices
+ * work concurrently (one host thread per device inside a call); the exchanges run over RCCL, which the library loads
+ * at run time (dlopen librccl.so.1, ncclCommInitAll over all devices).  With one device and no RCCL the calls still work
+ * (the exchange is the identity); with several devices and no RCCL boss_init fails (BOSS_E_NO_DEVICE).
+ *
+ * boss_init          enumerate the visible devices (BOSS_MAX_DEVICES in the environment caps the count), open a context
+ *                    and a communicator on each.  Idempotent.  Replaces nothing in the reference (its parallelism is
+ *                    Threads.@threads on the host: src/utils/optim_multistart.jl:61-90).
+ * boss_comm_info     number of devices opened by boss_init and whether the exchanges run over RCCL.
+ * boss_shutdown      destroy the communicators and exchange buffers (posterior handles are the caller's to free first). */
+int  boss_init(int* n_devices_out);
+int  boss_comm_info(int* n_devices_out, int* rccl_out);
+void boss_shutdown(void);
+/* The same hyper-parameters on G replicas of one posterior (gps[g] created by boss_gp_create on device g): every
+ * device factorises concurrently; *logpdf_out from replica 0 (the factorisation is deterministic: all replicas agree). */
+int boss_multi_gp_update(int G, boss_gp_t* const* gps, const double* lengthscale, double amplitude, double noise_std,
+                         const double* mean_X, double* logpdf_out);
+/* Candidates sharded over G devices (BASELINE config 3).  Replaces the same loop as boss_acq_ei
+ * (src/acquisition_maximizers/sampling.jl:43-57) with the candidate columns split M/G:
+ *   gps      G×S×P handles, gps[p + P*(s + S*g)] = replica on device g of output p, sample s;
+ *   Xs       d×M candidates on the host; device g evaluates the contiguous, balanced shard g of the columns;
+ *   mean_Xs, fit_coefs, y_max, has_best/best, valid_mask, acq_out (M values or NULL): as boss_acq_ei, for all M;
+ *   argmax_out / max_out: the GLOBAL first-index arg-max — every device contributes its (max, global index) pair to ONE
+ *   RCCL all-gather (16 bytes per rank; RCCL has no MAXLOC), reduced with Julia's argmax rules (ties: smaller index,
+ *   NaN largest).  G must equal boss_init's count for the exchange to run over RCCL (a smaller G reduces on the host). */
+int boss_multi_acq_ei(int G, int P, int S, boss_gp_t* const* gps, int M, const double* Xs, const double* mean_Xs,
+                      const double* fit_coefs, const double* y_max, int has_best, double best,
+                      const unsigned char* valid_mask, double* acq_out, long* argmax_out, double* max_out);
+/* Outputs sharded (BASELINE config 4: "outputs sharded one-per-GPU"): gps[p + P*s] may live on ANY device opened by
+ * boss_init (model_posterior_slice per output, src/models/gaussian_process.jl:133-141, fitted where it lives).  Each
+ * owner predicts its (mu, var) rows for all M candidates; the rows travel in ONE RCCL all-reduce(sum) over zero-filled
+ * blocks (exact), then the EI x feasibility epilogue and the arg-max run on the device of gps[0]
+ * (expected_improvement.jl:68-90).  Arguments as boss_acq_ei with host candidates. */
+int boss_multi_acq_ei_outputs(int P, int S, boss_gp_t* const* gps, int M, const double* Xs, const double* mean_Xs,
+                              const double* fit_coefs, const double* y_max, int has_best, double best,
+                              const unsigned char* valid_mask, double* acq_out, long* argmax_out, double* max_out);
+/* Hyper-parameter samples sharded (BASELINE config 5): all P outputs of sample s live on one device, different samples
+ * on different devices.  Every device sums acq_s(x_j) over ITS samples; ONE RCCL all-reduce(sum) of M doubles; the mean
+ * over S (src/acquisitions/expected_improvement.jl:87-90), make_safe mask and arg-max on the device of sample 0. */
+int boss_multi_acq_ei_samples(int P, int S, boss_gp_t* const* gps, int M, const double* Xs, const double* mean_Xs,
+                              const double* fit_coefs, const double* y_max, int has_best, double best,
+                              const unsigned char* valid_mask, double* acq_out, long* argmax_out, double* max_out);
+/* boss_gp_loglike_batch with the S hyper-parameter sets split over devices 0..G-1 (contiguous, balanced); no collective:
+ * every device writes its slice of ll_out / status_out. */
+int boss_multi_loglike_batch(int G, int kernel, int d, int N, const double* X, const double* y, const double* mean_X,
+                             int mean_stride, const unsigned char* discrete, int S, const double* lengthscales,
+                             const double* amplitudes, const double* noise_stds, double* ll_out, int* status_out);
+
 /* ---- measurement helpers (bench.py / profiles) ------------------------------------------ */
 /* issue-rate microbenchmark of v_mfma_f64_16x16x4_f64: every SIMD of the device issues
  * `iters` x 16 independent MFMAs; returns the achieved TFLOP/s (calibrates the fp64 MFMA peak

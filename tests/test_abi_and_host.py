@@ -174,3 +174,27 @@ def test_asm_ring_kernels_do_not_spill(tmp_path):
             found += 1
             assert agpr == 0 and scratch == 0 and vgpr <= 256, (name, agpr, scratch, vgpr)
     assert found >= 18
+
+
+def test_integration_doc_shows_the_shipped_julia_glue():
+    """INTEGRATION.md embeds boss.jl_amd/julia/BOSSHip.jl verbatim (the binding a BOSS.jl maintainer adds); the glue declares
+    its own parameter type — `update_parameters!` asserts typeof(problem.model) <: M for FittedParams{M}
+    (/root/reference/src/types/problem.jl:177-179) — passes prior means to the acquisition and binds every entry point it calls."""
+    jl = open(os.path.join(ROOT, "boss.jl_amd", "julia", "BOSSHip.jl")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert jl in doc
+    assert "struct HipGPParams" in jl and "<: BOSS.ModelParams{HipGaussianProcess}" in jl
+    assert "const HipGPParams = BOSS.GaussianProcessParams" not in jl
+    assert "prior_means(posts, xs)" in jl and "finalizer(close, obj)" in jl
+    syms = set(header_symbols())
+    called = set(re.findall(r"\(:(boss_[a-z0-9_]+), lib\)", jl))
+    assert called and called <= syms, called - syms
+    for must in ("boss_gp_fit", "boss_gp_update", "boss_gp_predict", "boss_acq_ei", "boss_multi_acq_ei", "boss_init", "boss_gp_loglike_batch"):
+        assert must in called, must
+    # every ccall passes as many arguments as its type tuple declares
+    for m in re.finditer(r"ccall\(\(:(boss_[a-z0-9_]+), lib\), (\w+),\s*\(([^)]*)\)", jl, re.S):
+        name, types = m.group(1), [t for t in m.group(3).replace("\n", " ").split(",") if t.strip()]
+        hdr = re.search(r"\b" + name + r"\s*\(([^;]*?)\);", re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bosship.h")).read(), flags=re.S), re.S)
+        assert hdr, name
+        nargs = 0 if hdr.group(1).strip() in ("", "void") else hdr.group(1).count(",") + 1
+        assert len(types) == nargs, (name, len(types), nargs)

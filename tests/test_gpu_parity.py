@@ -682,6 +682,82 @@ def test_ei_from_moments_and_shard_modes(api, O):
         assert np.array_equal(x, Xs[:, j]) and abs(val - want[j]) <= 1e-12, mode
 
 
+def test_multi_device_entry_points(api, O):
+    """boss_init + boss_multi_*: ONE process driving the devices, exchanges over RCCL inside the library (what a Julia caller
+    uses to shard without torch).  The test box has one GPU, so G = 1 here — the degenerate communicator still runs every
+    collective (ncclCommInitAll over one device, all-gather of the 16-byte pair, all-reduce of the moment rows / partial sums) —
+    plus host-side sharding over G = 1 of a larger communicator's code path via a candidate count that is not a multiple of
+    anything.  Each mode against the single-device entry point and the oracle; then through HipBatchAM(devices=[0])."""
+    import boss_jl_amd as B
+    n = api.init()
+    assert n >= 1 and api.init() == n                       # idempotent
+    ndev, rccl = api.comm_info()
+    assert ndev == n and rccl, "RCCL must load on the GPU box"
+    rng = np.random.default_rng(33)
+    d, N, M, P, S = 3, 150, 211, 2, 3
+    X = rng.uniform(0, 1, (d, N))
+    Y = np.stack([np.sin(3 * X).sum(0), np.cos(2 * X).sum(0) - 1.0])
+    Xs = np.asfortranarray(rng.uniform(-0.1, 1.1, (d, M)))
+    y_max, coefs = np.array([np.inf, 0.3]), [1.0, 0.5]
+    lam = [np.exp(-0.5 + 0.2 * rng.standard_normal((d, P))) for _ in range(S)]
+    amp = [np.exp(0.2 * rng.standard_normal(P)) for _ in range(S)]
+    mX = [0.1 * X.sum(0), -0.2 * X[0]]
+    mS = np.stack([np.stack([0.1 * Xs.sum(0), -0.2 * Xs[0]])] * S)                       # S×P×M
+    posts = [[O.gp_fit(X, Y[p], "matern52", lam[s][:, p], amp[s][p], 0.05, mean=mX[p]) for p in range(P)] for s in range(S)]
+    b = O.best_so_far(coefs, Y, y_max)
+    mask = O.in_bounds(Xs, [0.] * d, [1.] * d)
+    want = O.ei_acquisition(posts, Xs, coefs, y_max, b, valid_mask=mask, means_s=[mS[0, 0], mS[0, 1]])
+    # replicas through boss_multi_gp_update (every device factorises concurrently)
+    gps = [[api.GP(X, Y[p], "matern52") for p in range(P)] for s in range(S)]
+    for s in range(S):
+        for p in range(P):
+            lp = api.multi_update([gps[s][p]], lam[s][:, p], amp[s][p], 0.05, mX[p])
+            assert abs(lp - posts[s][p].logpdf) <= 1e-9 * (1 + abs(posts[s][p].logpdf))
+    single = api.acq_ei(gps, api.Candidates(Xs), coefs, y_max, b, mask, mS)
+    for fn, arg in ((api.multi_acq_ei, [gps]), (api.multi_acq_ei_outputs, gps), (api.multi_acq_ei_samples, gps)):
+        acq, am, mx = fn(arg, Xs, coefs, y_max, b, mask, mS)
+        assert np.allclose(acq, want, rtol=0, atol=1e-10), fn.__name__
+        assert np.allclose(acq, single[0], rtol=0, atol=1e-13) and (am, mx) == (single[1], acq[am]), fn.__name__
+        assert am == int(np.argmax(acq))
+        _, am2, mx2 = fn(arg, Xs, coefs, y_max, b, mask, mS, want_acq=False)
+        assert (am2, mx2) == (am, mx)
+    # the four construct_ei variants through the sharded entry point
+    for ym_, b_ in ((None, None), (y_max, None), (None, b)):
+        a1, _, _ = api.multi_acq_ei([gps], Xs, coefs, ym_, b_, None, mS)
+        assert np.allclose(a1, O.ei_acquisition(posts, Xs, coefs, ym_, b_, means_s=[mS[0, 0], mS[0, 1]]), rtol=0, atol=1e-10)
+    # errors: a sample whose outputs sit on different devices cannot happen with one GPU; unfitted handles and bad counts can
+    g_un = api.GP(X, Y[0], "matern52")
+    with pytest.raises(api.BossError) as e:
+        api.multi_acq_ei_outputs([[g_un]], Xs, [1.0])
+    assert e.value.code == api.BOSS_E_NOT_FITTED
+    with pytest.raises(api.BossError):
+        api.multi_acq_ei([gps] * (n + 1), Xs, coefs)       # more replicas than devices
+    g_un.close()
+    # likelihood batch split over the devices == the single-device batch
+    lamS = np.exp(-0.7 + 0.3 * rng.standard_normal((d, 7)))
+    ampS, sigS = np.exp(0.3 * rng.standard_normal(7)), np.full(7, 0.05)
+    ll_m, st_m = api.multi_loglike_batch(1, X, Y[0], "matern52", lamS, ampS, sigS, mean_X=mX[0])
+    ll_1, st_1 = api.loglike_batch(X, Y[0], "matern52", lamS, ampS, sigS, mean_X=mX[0])
+    assert np.array_equal(ll_m, ll_1) and np.array_equal(st_m, st_1)
+    # the plugin mirror in single-process mode
+    prm = [B.HipGPParams(lam[s], amp[s], np.full(P, 0.05)) for s in range(S)]
+    model = B.HipGaussianProcess([None] * P, [None] * P, [None] * P, mean=lambda x: [0.1 * x.sum(), -0.2 * x[0]])
+    prob = B.BossProblem(None, B.Domain((np.zeros(d), np.ones(d))), B.ExpectedImprovement(B.LinFitness(coefs)), model,
+                         B.ExperimentData(X, Y), y_max, prm)
+    j = int(np.argmax(want))
+    for mode in ("candidates", "outputs", "samples"):
+        amx = B.HipBatchAM(points=Xs, shard=mode, devices=[0])
+        x, val = amx.maximize_acquisition(prob)
+        _, allv = amx.maximize_acquisition(prob, return_all=True)
+        assert np.allclose(allv, want, rtol=0, atol=1e-10), mode
+        assert np.array_equal(x, Xs[:, j]) and abs(val - want[j]) <= 1e-10, mode
+    for row in gps:
+        for g in row:
+            g.close()
+    api.shutdown()
+    assert api.init() == n                                  # re-initialisation after a shutdown
+
+
 @pytest.mark.parametrize("N0,steps", [(5, [1, 1, 3]), (100, [1]), (127, [2]), (128, [1]), (130, [1, 1, 1]), (255, [1, 130]),
                                       (300, [40, 100]), (256, [600]), (640, [1, 1]), (255, [33]), (250, [7, 300])])
 def test_block_cholesky_append(api, O, N0, steps):
