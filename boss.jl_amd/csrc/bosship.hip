@@ -115,7 +115,27 @@ static int ctx_init(Ctx* c) {
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest));
         c->stream = c->own_stream;
-        HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
+        // The bulk trailing updates run on a stream whose CU mask leaves every (ncu / reserve)-th CU alone: their 128×128
+        // tiles fill the register files of the CUs they run on for tens of microseconds, and a chain kernel that has to
+        // wait for such a tile to retire (the diagonal block needs a whole CU) or shares a SIMD's matrix pipe with one
+        // (the panel solve) stalls the whole factorisation (device timeline: +20 µs per affected step).  With reserved
+        // CUs the chain kernels always find an idle CU.  Measured (profiles/r02_chain_timeline_*.log): the stalls are NOT a
+        // lack of free CUs — with 32 or 64 reserved CUs the solve / column-update kernels of the steps that overlap a bulk
+        // update are just as slow (32 µs instead of 9) — so the mask is off by default (BOSS_BULK_RESERVE=n turns it on).
+        static const int reserve = getenv("BOSS_BULK_RESERVE") ? atoi(getenv("BOSS_BULK_RESERVE")) : 0;
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, c->device));
+        const int ncu = prop.multiProcessorCount;
+        bool masked = false;
+        if (reserve > 0 && reserve < ncu) {
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            const int every = ncu / reserve;
+            for (int i = 0; i < ncu; ++i)
+                if (i % every != 0) mask[i / 32] |= 1u << (i % 32);
+            masked = hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (!masked) (void)hipGetLastError();
+        }
+        if (!masked) HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));

@@ -44,8 +44,9 @@ extern "C" int boss_debug_trace(unsigned long long* out, unsigned int* n, int re
 '''
 open(p, "w").write(s)
 out = os.path.join(ROOT, "tools", "libbosship_tr.so")
-cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-w",
-       "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-o", out, p]
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + entry.HIPCC_FLAGS + ["-o", out, p]
 subprocess.check_call(cmd)
 shutil.rmtree(tmp)
 print("built", out)

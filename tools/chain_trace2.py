@@ -1,0 +1,93 @@
+"""Device-side timeline of one N=4096 posterior update with WHOLE-KERNEL extents: every workgroup of the chain kernels
+(diag / solve / column update) and of the bulk trailing update stamps s_memrealtime at entry and exit; per (kernel, panel k)
+the earliest entry and the latest exit are kept (atomicMin / atomicMax).  Prints absolute start / end per step.
+Build: python tools/chain_trace2.py --build   (instrumented copy; the product sources are not modified)."""
+import os, shutil, subprocess, sys, tempfile, ctypes as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def build():
+    tmp = tempfile.mkdtemp(prefix="bosship_t2_")
+    os.makedirs(os.path.join(tmp, "boss.jl_amd"))
+    shutil.copytree(os.path.join(ROOT, "boss.jl_amd", "csrc"), os.path.join(tmp, "boss.jl_amd", "csrc"))
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+    p = os.path.join(tmp, "boss.jl_amd", "csrc", "potrf.hpp")
+    s = open(p).read()
+    s = s.replace("constexpr int DIAG_THREADS = 1024;",
+                  "__device__ unsigned long long g_t0[8 * 64], g_t1[8 * 64];\n"
+                  "#define TR_BEGIN(code, kk) const int tr_i_ = (code) * 64 + ((kk) & 63); if (threadIdx.x == 0 && blockIdx.z == 0) "
+                  "atomicMin(&g_t0[tr_i_], (unsigned long long)__builtin_amdgcn_s_memrealtime());\n"
+                  "#define TR_END() if (threadIdx.x == 0 && blockIdx.z == 0) atomicMax(&g_t1[tr_i_], (unsigned long long)__builtin_amdgcn_s_memrealtime());\n"
+                  "constexpr int DIAG_THREADS = 1024;", 1)
+    s = s.replace("    extern __shared__ double smem[];\n    double* D = smem;", "    TR_BEGIN(1, k);\n    extern __shared__ double smem[];\n    double* D = smem;", 1)
+    i = s.index("    // ---- write L: 16-byte stores")
+    j = s.index("\n}\n", i)
+    s = s[:j] + "\n    __syncthreads();\n    TR_END();" + s[j:]
+    for code, head in ((2, "__global__ __launch_bounds__(64) void potrf_trsm_kernel("),
+                       (3, "__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel("),
+                       (4, "__global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(")):
+        i = s.index(head)
+        kpos = s.index("{\n", i) + 2
+        s = s[:kpos] + f"    TR_BEGIN({code}, k);\n" + s[kpos:]
+        j = s.index("\n}\n", kpos)
+        s = s[:j] + "\n    TR_END();" + s[j:]
+    open(p, "w").write(s)
+    p = os.path.join(tmp, "boss.jl_amd", "csrc", "bosship.hip")
+    s = open(p).read() + '''
+extern "C" int boss_debug_trace2(unsigned long long* t0, unsigned long long* t1, int reset) {
+    if (hipMemcpyFromSymbol(t0, HIP_SYMBOL(boss::g_t0), 8 * 8 * 64) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(t1, HIP_SYMBOL(boss::g_t1), 8 * 8 * 64) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long ones[8 * 64], zeros[8 * 64];
+        for (int i = 0; i < 8 * 64; ++i) { ones[i] = ~0ull; zeros[i] = 0; }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(boss::g_t0), ones, sizeof ones);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(boss::g_t1), zeros, sizeof zeros);
+    }
+    return 0;
+}
+'''
+    open(p, "w").write(s)
+    out = os.path.join(ROOT, "tools", "libbosship_t2.so")
+    import __graft_entry__ as entry
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + entry.HIPCC_FLAGS + ["-o", out, p])
+    shutil.rmtree(tmp)
+    return out
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        print("built", build())
+        sys.exit(0)
+    from boss_jl_amd import api
+    lib = api.load_library(os.path.join(ROOT, "tools", "libbosship_t2.so"))
+    lib.boss_debug_trace2.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (8, N)); y = np.sin(X).sum(0)
+    g = api.GP(X, y, "matern52")
+    for _ in range(3):
+        g.update(np.full(8, .5), 1.0, 0.05)
+    t0 = (C.c_ulonglong * 512)(); t1 = (C.c_ulonglong * 512)()
+    lib.boss_debug_trace2(t0, t1, 1)
+    g.update(np.full(8, .5), 1.0, 0.05)
+    api.device_sync(0)
+    lib.boss_debug_trace2(t0, t1, 0)
+    a0 = np.array(t0[:], dtype=np.float64).reshape(8, 64); a1 = np.array(t1[:], dtype=np.float64).reshape(8, 64)
+    valid = a1 > 0
+    base = a0[valid].min()
+    names = {1: "diag", 2: "solve", 3: "colupd", 4: "bulk"}
+    print(f"N={N}; times in µs from the first chain kernel's entry; whole-kernel extents (earliest workgroup entry .. latest exit)")
+    print(" k | diag start..end | solve start..end | colupd start..end | bulk start..end")
+    nblk = (N + 255) // 256 * 2
+    for k in range(nblk):
+        row = [f"{k:2d}"]
+        for code in (1, 2, 3, 4):
+            if valid[code, k]:
+                row.append(f"{(a0[code, k]-base)/100:7.1f}..{(a1[code, k]-base)/100:7.1f}")
+            else:
+                row.append(" " * 16)
+        print(" | ".join(row))
+    print(f"span {(a1[valid].max()-base)/100:.1f} µs")
