@@ -17,17 +17,20 @@ def build():
     p = os.path.join(tmp, "boss.jl_amd", "csrc", "potrf.hpp")
     s = open(p).read()
     s = s.replace("constexpr int DIAG_THREADS = 1024;",
-                  "__device__ unsigned long long g_t0[8 * 64], g_t1[8 * 64];\n"
+                  "__device__ unsigned long long g_t0[8 * 64], g_t1[8 * 64];\n__device__ unsigned int g_cu[2 * 8 * 4 * 16];\n"
                   "#define TR_BEGIN(code, kk) const int tr_i_ = (code) * 64 + ((kk) & 63); if (threadIdx.x == 0 && blockIdx.z == 0) "
-                  "atomicMin(&g_t0[tr_i_], (unsigned long long)__builtin_amdgcn_s_memrealtime());\n"
+                  "{ atomicMin(&g_t0[tr_i_], (unsigned long long)__builtin_amdgcn_s_memrealtime()); unsigned xc_, hw_; "
+                  "asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xc_)); asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw_)); "
+                  "atomicAdd(&g_cu[((((code) == 4 ? 1 : 0) * 8 + (xc_ & 7)) * 4 + ((hw_ >> 13) & 3)) * 16 + ((hw_ >> 8) & 15)], 1u); }\n"
                   "#define TR_END() if (threadIdx.x == 0 && blockIdx.z == 0) atomicMax(&g_t1[tr_i_], (unsigned long long)__builtin_amdgcn_s_memrealtime());\n"
                   "constexpr int DIAG_THREADS = 1024;", 1)
     s = s.replace("    extern __shared__ double smem[];\n    double* D = smem;", "    TR_BEGIN(1, k);\n    extern __shared__ double smem[];\n    double* D = smem;", 1)
     i = s.index("    // ---- write L: 16-byte stores")
     j = s.index("\n}\n", i)
     s = s[:j] + "\n    __syncthreads();\n    TR_END();" + s[j:]
-    for code, head in ((2, "__global__ __launch_bounds__(64) void potrf_trsm_kernel("),
+    for code, head in (("(row0 == (k + 1) * BLK && gridDim.x == 8) ? 5 : 2", "__global__ __launch_bounds__(64) void potrf_trsm_kernel("),
                        (3, "__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel("),
+                       (6, "__global__ __launch_bounds__(256) void potrf_diagupd_kernel("),
                        (4, "__global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(")):
         i = s.index(head)
         kpos = s.index("{\n", i) + 2
@@ -37,6 +40,7 @@ def build():
     open(p, "w").write(s)
     p = os.path.join(tmp, "boss.jl_amd", "csrc", "bosship.hip")
     s = open(p).read() + '''
+extern "C" int boss_debug_cus(unsigned int* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(boss::g_cu), 4 * 2 * 8 * 4 * 16) == hipSuccess ? 0 : 1; }
 extern "C" int boss_debug_trace2(unsigned long long* t0, unsigned long long* t1, int reset) {
     if (hipMemcpyFromSymbol(t0, HIP_SYMBOL(boss::g_t0), 8 * 8 * 64) != hipSuccess) return 1;
     if (hipMemcpyFromSymbol(t1, HIP_SYMBOL(boss::g_t1), 8 * 8 * 64) != hipSuccess) return 1;
@@ -52,7 +56,8 @@ extern "C" int boss_debug_trace2(unsigned long long* t0, unsigned long long* t1,
     open(p, "w").write(s)
     out = os.path.join(ROOT, "tools", "libbosship_t2.so")
     import __graft_entry__ as entry
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + entry.HIPCC_FLAGS + ["-o", out, p])
+    extra = os.environ.get("BOSS_EXTRA_FLAGS", "").split()
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + entry.HIPCC_FLAGS + extra + ["-o", out, p])
     shutil.rmtree(tmp)
     return out
 
@@ -78,16 +83,26 @@ if __name__ == "__main__":
     a0 = np.array(t0[:], dtype=np.float64).reshape(8, 64); a1 = np.array(t1[:], dtype=np.float64).reshape(8, 64)
     valid = a1 > 0
     base = a0[valid].min()
-    names = {1: "diag", 2: "solve", 3: "colupd", 4: "bulk"}
+    names = {1: "diag", 5: "solveA", 6: "diagupd", 2: "solve(B)", 3: "colupd(B)", 4: "bulk"}
     print(f"N={N}; times in µs from the first chain kernel's entry; whole-kernel extents (earliest workgroup entry .. latest exit)")
-    print(" k | diag start..end | solve start..end | colupd start..end | bulk start..end")
+    print(" k | " + " | ".join(f"{names[c_]:>16s}" for c_ in (1, 5, 6, 2, 3, 4)))
     nblk = (N + 255) // 256 * 2
     for k in range(nblk):
         row = [f"{k:2d}"]
-        for code in (1, 2, 3, 4):
+        for code in (1, 5, 6, 2, 3, 4):
             if valid[code, k]:
                 row.append(f"{(a0[code, k]-base)/100:7.1f}..{(a1[code, k]-base)/100:7.1f}")
             else:
                 row.append(" " * 16)
         print(" | ".join(row))
     print(f"span {(a1[valid].max()-base)/100:.1f} µs")
+    cu = (C.c_uint * (2 * 8 * 4 * 16))()
+    lib.boss_debug_cus.argtypes = [C.POINTER(C.c_uint)]
+    lib.boss_debug_cus(cu)
+    cu = np.array(cu[:]).reshape(2, 8, 4, 16)
+    for kind, nm in ((0, "chain kernels"), (1, "bulk")):
+        used = cu[kind] > 0
+        print(f"{nm}: workgroups ran on {int(used.sum())} distinct CUs; per XCD: {[int(used[x].sum()) for x in range(8)]}")
+    only_chain = (cu[0] > 0) & (cu[1] == 0)
+    print("CUs that ran chain workgroups but never a bulk workgroup:", int(only_chain.sum()), "per XCD", [int(only_chain[x].sum()) for x in range(8)])
+    print("chain workgroups on those CUs:", int(cu[0][only_chain].sum()), "of", int(cu[0].sum()))
