@@ -185,6 +185,9 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -286,6 +289,7 @@ struct boss_gp {
     bool has_mean = false, fitted = false, pending = false, have_dinv = false;
     bool dinv_used = false;                    // the current block inverses were used by a prediction (see factor_enqueue)
     double* host_res = nullptr;                // pinned: scal[2], info
+    double* host_res_dev = nullptr;            // the same memory through its device address (written by small_fit_kernel)
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
     unsigned long long epoch = 0;              // bumped by every boss_gp_update: tracked candidate states go stale

@@ -16,8 +16,6 @@
 
 namespace boss {
 
-constexpr int LDD = 144;                               // LDS leading dim of the diagonal block
-constexpr int DIAG_LDS_BYTES = (BLK * LDD + 256) * 8;  // block + E tile of the current panel
 
 // ------------------------------------------------------------------------------------------
 // Diagonal block: unblocked 16-column panels (lane = row, pivots broadcast with v_readlane),
@@ -30,135 +28,165 @@ constexpr int DIAG_LDS_BYTES = (BLK * LDD + 256) * 8;  // block + E tile of the 
 // this wave's outstanding global stores (inv16 goes to global right before barrier 1).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int DIAG_THREADS = 1024;   // 16 waves = 4 per SIMD: single-wave fp64 VALU / LDS / MFMA issue rates are 3-5x below the multi-wave rates
 
 // 16×16 tile in the "transposed C" layout: register i of lane l = element (row = l&15, col = (l>>4)+4i),
 // so register t IS the 16×4 micro-panel of columns 4t..4t+3 in MFMA A/B-operand layout.
 //
-// chol16_with_inverse: factor the symmetric-filled tile S in place (lower part = L16) and carry the
-// identity tile E through the same column operations, which leaves E = L16^{-T} (so inv(L16) comes
-// out of the factorisation itself).  This runs on ONE wave, and a lone wave pays ≈12 cycles per fp64
-// VALU instruction and ≈5 per 32-bit one whether or not they depend on each other — so the code
-// minimises the instruction COUNT per column: the column's entries reach the lanes that need them by
-// three ds_bpermute (issued before the 1/sqrt(p) refinement, which hides their latency) instead of
-// v_readlane/select chains, the update is one unconditional fma per tile with a pre-masked factor,
-// and the scaling of the finished columns is deferred to the end of the 4-column micro-panel.  Then
-// ONE rank-4 MFMA per tile updates the remaining columns.
-__device__ __forceinline__ void chol16_with_inverse(v4d& S, v4d& E, int lane, int col0, int& fail) {
+// chol16_unscaled: the sequential pivot chain of one diagonal tile, WITHOUT square roots.  It runs on ONE wave, and a
+// lone wave pays ≈12 cycles per fp64 VALU instruction and ≈5 per 32-bit one whether or not they depend on each other —
+// so the code minimises the instruction COUNT on this wave and leaves everything that can wait to other waves:
+//   * the tile is factored in the UNSCALED form S' = L16·diag(√p) (column c of L16 times its pivot's root): eliminating
+//     column j from the later columns needs only 1/p_j (v_rcp_f64 + one cubic correction: 4 instructions; 1/√p cost 6
+//     plus a squaring), and the diagonal of S' holds the pivots themselves, S'(c,c) = p_c;
+//   * the identity tile E rides along through the same column operations and ends as E' = L16^{-T}·diag(√p);
+//   * the column's entries reach the lanes that need them by three ds_bpermute (issued before the reciprocal's
+//     refinement, which hides their latency), the update is one unconditional fma per tile with a pre-masked factor;
+//   * after each 4-column micro-panel ONE rank-4 MFMA per tile updates the remaining columns, its A operand scaled by
+//     1/p of its column (ipsel) instead of both operands by 1/√p.
+// The 1/√p scaling of L16, of L16^{-1} and of the row tiles below is applied by the waves that consume S' and E'
+// (they derive it from the diagonal of S'), so no square root is ever computed on the chain.
+// ipsel[t] of lane l returns 1/p of column 4t + (l>>4).
+__device__ __forceinline__ void chol16_unscaled(v4d& S, v4d& E, double (&ipsel)[4], int lane, int col0, int& fail) {
     const int r16 = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) E[i] = (r16 == q + 4 * i) ? 1.0 : 0.0;
+    bool bad = false;
+    int badcol = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        double rs[4];
+        ipsel[t] = 1.0;
+        // The chain is LATENCY-bound (≈9 dependent instructions per column at ≈23 cycles each when every pivot is read back
+        // from the updated tile): the next pivot is therefore advanced as a wave-uniform scalar recurrence
+        //     p_{j+1} = S(j+1,j+1) − S(j+1,j)·(S(j+1,j)/p_j)
+        // from two entries read BEFORE column j is eliminated — the same two operations the owning lane performs, so it
+        // equals the tile's diagonal entry bit for bit — and the reciprocal of p_{j+1} starts while the vector update of
+        // column j is still in flight.  Dependent path per column: mul, fma, rcp, 3 × fma.
+        double p = readlane_f64(S[t], 4 * t);                       // S(4t, 4t): lane (r16 = 4t, q = 0)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            double p = readlane_f64(S[t], 16 * j + 4 * t + j);
-            double lS = 0.0, lE = 0.0, lc = 0.0;
+            double dn = 0.0, ln = 0.0, lS = 0.0, lE = 0.0, lc = 0.0;
             if (j < 3) {
-                // column j is still UNSCALED (= L(:,j)·sqrt(p)):  X(r,c) -= X(r,j)·S(c,j) / p  for the columns c > j
-                lS = __shfl(S[t], 16 * j + r16);            // S(r, j): same row, column j
+                dn = readlane_f64(S[t], 16 * (j + 1) + 4 * t + j + 1);      // S(c+1, c+1), c = 4t+j, eliminations < j applied
+                ln = readlane_f64(S[t], 16 * j + 4 * t + j + 1);            // S(c+1, c)
+                // X(r,c') -= X(r,c)·S(c',c) / p  for the columns c' > c of this micro-panel
+                lS = __shfl(S[t], 16 * j + r16);            // S(r, c): same row, column j of the micro-panel
                 lE = __shfl(E[t], 16 * j + r16);
-                lc = __shfl(S[t], 16 * j + 4 * t + q);      // S(c, j) for this lane's own column c = 4t+q
+                lc = __shfl(S[t], 16 * j + 4 * t + q);      // S(c', c) for this lane's own column c' = 4t+q
             }
-            if (!(p > 0.0)) {                      // NaN or non-positive pivot: not PD
-                if (fail < 0) fail = col0 + 4 * t + j;
-                p = 1.0;
+            if (!(p > 0.0) && !bad) {              // NaN or non-positive pivot: not PD (reported; the numbers that follow are garbage)
+                bad = true;
+                badcol = 4 * t + j;
             }
-            const double inv = rsqrt_refined(p);
-            rs[j] = inv;
+            const double ip = rcp_refined(p);
+            ipsel[t] = (q == j) ? ip : ipsel[t];
             if (j < 3) {
+                p = __builtin_fma(-ln, ln * ip, dn);                // next pivot, ahead of the tile update
                 const double lcm = (q > j) ? lc : 0.0;
-                const double m = lcm * (inv * inv);
+                const double m = lcm * ip;
                 S[t] = __builtin_fma(-lS, m, S[t]);
                 E[t] = __builtin_fma(-lE, m, E[t]);
             }
         }
-        const double sc = (q == 0) ? rs[0] : (q == 1) ? rs[1] : (q == 2) ? rs[2] : rs[3];
-        S[t] *= sc;
-        E[t] *= sc;
         if (t < 3) {
-            // rank-4 update of columns > 4t+3:  X(r,c) -= Σ_k X(r,4t+k) · S(c,4t+k)
-            const double am = (r16 > 4 * t + 3) ? -S[t] : 0.0;
+            // rank-4 update of columns > 4t+3:  X(r,c) -= Σ_k X(r,4t+k) · S(c,4t+k) / p_{4t+k}
+            const double am = (r16 > 4 * t + 3) ? -S[t] * ipsel[t] : 0.0;
             const double bS = S[t], bE = E[t];
             S = mfma_f64(am, bS, S);
             E = mfma_f64(am, bE, E);
         }
     }
+    if (bad && fail < 0) fail = col0 + badcol;
 }
+
+// Lane-private staging of a 16×16 tile held in the layout above: lane (r16, q) owns four consecutive doubles
+// (its columns q, q+4, q+8, q+12) at ((r16·4 + q)·4): two 16-byte LDS writes per tile on the chain wave instead of
+// four 8-byte ones, and element (row R, col C) is read back from ((R·4 + (C&3))·4 + (C>>2)) — conflict-free for the
+// MFMA operand pattern (row = 4s + (l>>4), col = l&15) of the consumers.
+__device__ __forceinline__ int lp_index(int R, int C) { return ((R * 4 + (C & 3)) * 4) + (C >> 2); }
 
 // ------------------------------------------------------------------------------------------
 // Diagonal block (128×128, LDS-resident), 16-column panels, look-ahead inside the block:
-//   phase A  wave 0 alone runs the sequential pivot chain on the diagonal 16×16 tile
-//            (chol16_with_inverse) — meanwhile waves 1..15 are still applying the PREVIOUS panel's
-//            rank-16 update to the rest of the block;
-//   phase B  waves 1..7-jb turn their row tile into P = X · inv(L16)^T with 4 MFMAs;
-//   phase C  wave 0 updates only the NEXT diagonal tile and goes straight back to phase A,
-//            the other waves update everything else.
+//   phase A  wave 0 alone runs the sequential pivot chain on the diagonal 16×16 tile (chol16_unscaled) — meanwhile the
+//            update waves are still applying the PREVIOUS panel's rank-16 update to the rest of the block;
+//   phase B  waves 1..7-jb turn the row tiles into P = X · inv(L16)^T (4 MFMAs with the unscaled E', then the 1/√p column
+//            scaling); wave 0 forms the first row tile unscaled, applies it to the NEXT diagonal tile (weights 1/p) and
+//            goes straight back to phase A; wave 15 scales S' and E' into L16 and inv(L16) and writes both to global.
+// The block lives in LDS as its 36 lower 16×16 tiles, tile-major (tile (i, j), i >= j, at (i(i+1)/2 + j)·256, column-major
+// inside): 74 KB instead of the 147 KB of a padded square, and only the lower tiles travel between global memory and LDS.
+// (Measured and rejected: 8 waves so that the kernel fits beside one bulk-update workgroup on every CU — co-residency with a
+// bulk wave on the pivot chain's SIMD stretches the kernel from 22 to 60 µs; it is better off waiting for an idle CU.)
 // inv16 out: for each of the 8 diagonal 16×16 blocks its inverse X (column-major 16×16,
 // X(r,c) at c*16+r, zero above the diagonal).
 // info: first failing global column + 1 (0 = success) — PosDefException analogue.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ Abase, int ld, size_t bstride,
-                                                                  int k, double* __restrict__ inv16base,
-                                                                  size_t inv16_bstride, int* __restrict__ info) {
-    extern __shared__ double smem[];
+constexpr int DIAG_THREADS = 1024;   // 16 waves = 4 per SIMD: single-wave fp64 VALU / LDS / MFMA issue rates are 3-5x below the multi-wave rates
+constexpr int DIAG_TILES = 36;
+constexpr int DIAG_STAGE = 2 * 256 + 2;                // doubles: unscaled E' and S' of the current panel (lane-private layout) + a flag word
+constexpr int DIAG_LDS_BYTES = (DIAG_TILES * 256 + DIAG_STAGE) * 8;
+__device__ __forceinline__ int dtile(int i, int j) { return (i * (i + 1) / 2 + j) * 256; }   // LDS offset of lower tile (i, j)
+
+// nsub: number of leading 16-column panels that hold observations (8 = the whole block); the panels behind them are
+// identity padding and are neither factored nor touched.
+// KEEP: the scaled diagonal tiles and their inverses additionally stay in LDS (tile slot (jb, jb), and Is + jb·256 in the
+// inv16 format) for a caller that goes on to solve with the factor inside the same kernel (small_fit_kernel).
+template <bool KEEP = false>
+__device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, double* __restrict__ A, int ld,
+                                                  double* __restrict__ inv16, int col0, int nsub, int& fail,
+                                                  double* __restrict__ Is = nullptr) {
     double* D = smem;
-    double* Es = smem + BLK * LDD;                   // E = L16^{-T} of the current panel, row-major 16×16
+    double* Es = smem + DIAG_TILES * 256;            // E' = L16^{-T}·diag(√p) of the current panel, lane-private layout
+    double* Ss = Es + 256;                           // S' = L16·diag(√p), lane-private layout
+    volatile int* xread = reinterpret_cast<volatile int*>(Ss + 256);   // panel whose first row tile wave 0 has finished reading
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: tile decode runs on the SALU
     const int r16 = lane & 15, q = lane >> 4;
     constexpr int NW = DIAG_THREADS / 64;
-    double* A = Abase + (size_t)blockIdx.z * bstride + (size_t)k * BLK * ((size_t)ld + 1);
-    double* inv16 = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
-
-    for (int idx = tid; idx < BLK * (BLK / 2); idx += DIAG_THREADS) {
-        int c = idx / (BLK / 2), rp = idx % (BLK / 2);
-        *reinterpret_cast<v2d*>(D + c * LDD + 2 * rp) = *reinterpret_cast<const v2d*>(A + (size_t)c * ld + 2 * rp);
-    }
-    __syncthreads();
-
-    int fail = -1;
+    if (tid == 0) *xread = 0;
     v4d S = {0.0, 0.0, 0.0, 0.0};
-    // loop-invariant per-lane LDS offsets of a diagonal tile relative to its corner (the pivot-chain
-    // wave pays ≈5 cycles per integer instruction too): symmetric-fill source, plain element, E slot
-    int osym[4], oel[4], oes[4];
+    // loop-invariant per-lane offsets inside a 16×16 tile (the pivot-chain wave pays ≈5 cycles per integer instruction
+    // too): symmetric-fill source of a diagonal tile, plain element (row r16, col q + 4i)
+    int osym[4], oel[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = q + 4 * i;
-        osym[i] = (r16 >= c) ? (c * LDD + r16) : (r16 * LDD + c);
-        oel[i] = c * LDD + r16;
-        oes[i] = r16 * 16 + c;
+        osym[i] = (r16 >= c) ? (c * 16 + r16) : (r16 * 16 + c);
+        oel[i] = c * 16 + r16;
     }
+    // consumers' read offsets into the staged tiles: E'(row = 4s + q, col = r16) and the pivots S'(c, c), c = q + 4i
+    int oe[4], od[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oe[i] = lp_index(4 * i + q, r16);
+        od[i] = lp_index(q + 4 * i, q + 4 * i);
+    }
+    const int olp = (r16 * 4 + q) * 4;               // this lane's own four doubles of a staged tile
     if (wave == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) S[i] = D[osym[i]];   // symmetric fill of diagonal tile 0 from its lower part
     }
-    for (int jb = 0; jb < 8; ++jb) {
-        const int t = 7 - jb;                         // row tiles below the diagonal tile
+    for (int jb = 0; jb < nsub; ++jb) {
+        const int t = nsub - 1 - jb;                  // row tiles below the diagonal tile
+        double ipsel[4];
         // ---------------- phase A ----------------
         if (wave == 0) {
             v4d E;
-            chol16_with_inverse(S, E, lane, k * BLK + jb * 16, fail);
-            double* Dt = D + jb * 16 * (LDD + 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Dt[oel[i]] = S[i];                    // whole tile: its strict upper part is scratch nobody reads
-                Es[oes[i]] = E[i];                    // E(row r16, col c) = inv(L16)(c, r16)
-            }
+            chol16_unscaled(S, E, ipsel, lane, col0 + jb * 16, fail);
+            *reinterpret_cast<v4d*>(Es + olp) = E;
+            *reinterpret_cast<v4d*>(Ss + olp) = S;
         } else if (jb > 0 && (wave & 3) != 0) {
-            // rest of the rank-16 update with panel jb-1 (tile (jb,jb) was done by wave 0 in phase C).
+            // rest of the rank-16 update with panel jb-1 (tile (jb,jb) was done by wave 0 in phase B).
             // Waves 4, 8, 12 share wave 0's SIMD: they stay idle here, so the pivot chain's MFMAs and
             // VALU ops never queue behind update MFMAs (measured: 5450 → 3980 cycles per 16-column chain).
-            const int jp = jb - 1, tp = 7 - jp;
+            const int jp = jb - 1, tp = nsub - 1 - jp;
             const int T = tp * (tp + 1) / 2;
-            constexpr int U = 2;
+            constexpr int U = 2;                                // (U = 3 would cover panel 0's 27 tiles in one round, but the extra registers slow every round: measured)
             constexpr int NUPD = NW - NW / 4;                   // 12 update waves
             const int uw = wave - 1 - (wave >> 2);              // 0..11
             for (int q0 = 1 + uw; q0 < T; q0 += U * NUPD) {     // update waves cover tile indices 1..T-1
                 int ti[U], tj[U];
                 bool ok[U];
                 v4d cr[U];
+                double* ct[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int qq = q0 + NUPD * u;
@@ -168,17 +196,17 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
                     const int b = qq - a * (a + 1) / 2;
                     ti[u] = ok[u] ? jp + 1 + a : jp + 2;
                     tj[u] = ok[u] ? jp + 1 + b : jp + 2;
+                    ct[u] = D + dtile(ti[u], tj[u]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) cr[u][i] = D[(tj[u] * 16 + q + 4 * i) * LDD + ti[u] * 16 + r16];
+                    for (int i = 0; i < 4; ++i) cr[u][i] = ct[u][oel[i]];
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    const int kc = (jp * 16 + 4 * s4 + q) * LDD + r16;
                     double af[U], bf[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        af[u] = D[kc + tj[u] * 16];
-                        bf[u] = D[kc + ti[u] * 16];
+                        af[u] = D[dtile(tj[u], jp) + oel[s4]];       // P(tj rows, k = q + 4s)
+                        bf[u] = D[dtile(ti[u], jp) + oel[s4]];
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) cr[u] = mfma_f64(-af[u], bf[u], cr[u]);
@@ -187,64 +215,279 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
                 for (int u = 0; u < U; ++u) {
                     if (ok[u]) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) D[(tj[u] * 16 + q + 4 * i) * LDD + ti[u] * 16 + r16] = cr[u][i];
+                        for (int i = 0; i < 4; ++i) ct[u][oel[i]] = cr[u][i];
                     }
                 }
             }
         }
-        lds_barrier();                                // barrier 1: L16/E published, block fully updated through panel jb-1
-        if (wave == 4) {                              // idle partner of the pivot-chain wave: inv(L16_jb) to global for it
+        lds_barrier();                                // barrier 1: S'/E' published, block fully updated through panel jb-1
+        if (wave == 15) {
+            // (a wave that has no row tile in phase B and does not share the pivot chain's SIMD) the scaled results of this panel's diagonal tile go to global from here —
+            // L16 = S'·diag(1/√p) into the factor, inv(L16) = (E'·diag(1/√p))^T into inv16 (for the panel solves)
+            const v4d Sv = *reinterpret_cast<const v4d*>(Ss + olp), Ev = *reinterpret_cast<const v4d*>(Es + olp);
+            double* At = A + (size_t)(jb * 16) * ((size_t)ld + 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) inv16[jb * 256 + lane + 64 * i] = Es[lane + 64 * i];
+            for (int i = 0; i < 4; ++i) {
+                const double rs = rsqrt_refined(Ss[od[i]]);          // 1/√p of column c = q + 4i
+                const int c = q + 4 * i;
+                if (r16 >= c) At[(size_t)c * ld + r16] = Sv[i] * rs;
+                inv16[jb * 256 + r16 * 16 + c] = Ev[i] * rs;        // inv(L16)(c, r16) = E(r16, c), stored at r16*16 + c
+                if constexpr (KEEP) {
+                    D[dtile(jb, jb) + oel[i]] = (r16 >= c) ? Sv[i] * rs : 0.0;
+                    Is[jb * 256 + r16 * 16 + c] = Ev[i] * rs;
+                }
+            }
         }
         if (t == 0) break;
         // ---------------- phase B: row tiles  P = X · inv(L16)^T ----------------
         if (wave == 0) {
-            // The pivot-chain wave owns the first row tile P(jb+1, jb) and applies it to the NEXT diagonal
-            // tile right away, so the next 16-column chain starts right behind barrier 2 (no separate
-            // phase C).  P stays in registers for that update: register s of the MFMA result is
-            // P(r, k = q + 4s), a valid k-slice for both operands of S -= P P^T.
+            // The pivot-chain wave forms the first row tile itself, UNSCALED (P' = X·E'^T = P·diag(√p)), and applies it to the
+            // NEXT diagonal tile right away with the weights 1/p (P' diag(1/p) P'^T = P P^T), so the next 16-column chain starts
+            // right behind barrier 2.  Register s of the MFMA result is P'(r, k = q + 4s): a valid k-slice for both operands.
+            // (The scaled tile that the rest of the block needs is written by wave 1.)
             const int tn = jb + 1;
             v4d P = {0.0, 0.0, 0.0, 0.0};
-            const double* Dx = D + jb * 16 * LDD + tn * 16;
-            const int oa = q * 16 + r16;
+            const double* Dx = D + dtile(tn, jb);
+            double aop[4], bop[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const double aop = Es[oa + 64 * s4];                 // inv(L16)(c = r16, k = 4s+q)
-                const double bop = Dx[oel[s4]];                      // X(r16, k = q+4s)
-                P = mfma_f64(aop, bop, P);
+                aop[s4] = Es[oe[s4]];                                // E'(k = 4s+q, c = r16)
+                bop[s4] = Dx[oel[s4]];                               // X(r16, k = q+4s)
             }
-            const double* Dn = D + tn * 16 * (LDD + 1);
+            const double* Dn = D + dtile(tn, tn);
 #pragma unroll
             for (int i = 0; i < 4; ++i) S[i] = Dn[osym[i]];
-            double* Dp = D + jb * 16 * LDD + tn * 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Dp[oel[i]] = P[i];
+            for (int s4 = 0; s4 < 4; ++s4) P = mfma_f64(aop[s4], bop[s4], P);      // (waits for the reads above)
+            if (lane == 0) *xread = jb + 1;            // wave 1 may now overwrite X(jb+1, jb) with the scaled tile
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) S = mfma_f64(-P[s4], P[s4], S);
-        } else if (wave < t) {
-            const int tr = jb + 1 + wave;              // waves 1..t-1 take the row tiles below wave 0's
+            for (int s4 = 0; s4 < 4; ++s4) S = mfma_f64(-P[s4] * ipsel[s4], P[s4], S);
+        } else if ((wave & 3) != 0 && wave - (wave >> 2) <= t) {
+            // row tiles jb+1..nsub-1 on the waves 1,2,3,5,6,7,9 — none on the pivot chain's SIMD (waves 4, 8, 12 stay idle: wave 0's
+            // own MFMAs and LDS traffic of this phase are the block's critical path)
+            const int wi = wave - (wave >> 2);         // 1..7
+            const int tr = jb + wi;
             v4d P = {0.0, 0.0, 0.0, 0.0};
+            double rs[4];
+            double* Xt = D + dtile(tr, jb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[i] = Ss[od[i]];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const double aop = Es[(4 * s4 + q) * 16 + r16];                       // inv(L16)(c = r16, k = 4s+q)
-                const double bop = D[(jb * 16 + q + 4 * s4) * LDD + tr * 16 + r16];   // X(r16, k = 4s+q)
+                const double aop = Es[oe[s4]];                       // E'(k = 4s+q, c = r16)
+                const double bop = Xt[oel[s4]];                      // X(r16, k = 4s+q)
                 P = mfma_f64(aop, bop, P);
             }
+            double pv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) D[(jb * 16 + q + 4 * i) * LDD + tr * 16 + r16] = P[i];
+            for (int i = 0; i < 4; ++i) pv[i] = P[i] * rsqrt_refined(rs[i]);
+            if (wi == 1) {
+                // this tile is also the operand wave 0 is reading for the next diagonal tile: do not overwrite it before
+                // wave 0 has its copy (wave 0 raises the flag right after its first MFMAs; it never waits for this wave)
+                while (*xread < jb + 1) __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Xt[oel[i]] = pv[i];
         }
         lds_barrier();                                // barrier 2: panel jb final
     }
-    if (wave == 0 && lane == 0 && fail >= 0) {
+}
+
+__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ Abase, int ld, size_t bstride,
+                                                                  int k, double* __restrict__ inv16base,
+                                                                  size_t inv16_bstride, int* __restrict__ info) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    double* A = Abase + (size_t)blockIdx.z * bstride + (size_t)k * BLK * ((size_t)ld + 1);
+    double* inv16 = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
+    // lower tiles global -> LDS, a wave per tile (36 tiles over 16 waves), 16-byte accesses: lane l moves the pairs l and l + 64
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int tl = wv; tl < DIAG_TILES; tl += DIAG_THREADS / 64) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
+        const int tj = tl - ti * (ti + 1) / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
+            *reinterpret_cast<v2d*>(smem + tl * 256 + c * 16 + 2 * rp) =
+                *reinterpret_cast<const v2d*>(A + (size_t)(tj * 16 + c) * ld + ti * 16 + 2 * rp);
+        }
+    }
+    __syncthreads();
+    int fail = -1;
+    diag_block_factor(smem, A, ld, inv16, k * BLK, 8, fail);
+    if (tid == 0 && fail >= 0) {
         if (info[blockIdx.z] == 0) info[blockIdx.z] = fail + 1;
     }
-    // ---- write L: 16-byte stores, skipping the 16×16 tiles strictly above the diagonal (the upper
-    //      triangles of the diagonal tiles carry scratch values; nothing reads them) ------------------
-    for (int idx = tid; idx < BLK * (BLK / 2); idx += DIAG_THREADS) {
-        int c = idx / (BLK / 2), rp = idx % (BLK / 2);
-        if ((2 * rp) / 16 >= c / 16)
-            *reinterpret_cast<v2d*>(A + (size_t)c * ld + 2 * rp) = *reinterpret_cast<const v2d*>(D + c * LDD + 2 * rp);
+    // ---- write L: the tiles strictly below the diagonal (the diagonal tiles went out from wave 15) ----
+    for (int tl = wv; tl < DIAG_TILES; tl += DIAG_THREADS / 64) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
+        const int tj = tl - ti * (ti + 1) / 2;
+        if (ti == tj) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
+            *reinterpret_cast<v2d*>(A + (size_t)(tj * 16 + c) * ld + ti * 16 + 2 * rp) =
+                *reinterpret_cast<const v2d*>(smem + tl * 256 + c * 16 + 2 * rp);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole posterior update in ONE launch for N <= 128 observations (BASELINE config 1: the reference's own example runs
+// with 3..20 points, examples/example.jl:117-162): scaled points, Gram tiles straight into LDS, the diagonal-block
+// factorisation above restricted to the ceil(N/16) panels that hold observations, z = L \ (y - m) by tile-wise
+// substitution, logdet and z^T z — and the results written into mapped host memory, so an update costs one kernel launch
+// and one stream synchronisation (the general path: 8 launches, two copies).  Replaces posterior_gp / logpdf
+// (src/models/gaussian_process.jl:199-211,269-280) for small data sets; outputs are the same arrays every other entry
+// point reads (factor, z row, inv16, scaled points, resident hyper-parameters).
+// ------------------------------------------------------------------------------------------
+constexpr int SMALL_MAX_N = BLK, SMALL_MAX_D = 32;
+struct SmallFitPar {
+    int d, N, Np, ld, kern;
+    double amp2, sig2;
+    double invlam[SMALL_MAX_D];
+};
+constexpr int SMALL_LDS_DOUBLES = DIAG_TILES * 256 + DIAG_STAGE + 2 + 8 * 256 + SMALL_MAX_D * SMALL_MAX_N + 2 * SMALL_MAX_N + 8;
+constexpr int SMALL_LDS_BYTES = SMALL_LDS_DOUBLES * 8;
+
+__global__ __launch_bounds__(DIAG_THREADS) void small_fit_kernel(SmallFitPar par, const double* __restrict__ Xraw,
+                                                                 double* __restrict__ Xsc, const double* __restrict__ y,
+                                                                 const double* __restrict__ mean, double* __restrict__ A,
+                                                                 double* __restrict__ inv16, double* __restrict__ par_dev,
+                                                                 double* __restrict__ scal, int* __restrict__ info,
+                                                                 double* __restrict__ host_res) {
+    extern __shared__ double smem[];
+    double* Is = smem + DIAG_TILES * 256 + DIAG_STAGE + 2;   // scaled inverses of the diagonal tiles (inv16 format), 8 × 256
+    double* xs = Is + 8 * 256;                               // scaled points [d][128]
+    double* rhs = xs + SMALL_MAX_D * SMALL_MAX_N;            // y - m (then overwritten tile by tile with z)
+    double* red = rhs + 2 * SMALL_MAX_N;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int d = par.d, N = par.N, Np = par.Np, ld = par.ld;
+    const int nsub = (N + 15) / 16;
+    // resident copies of the hyper-parameters for the entry points that follow (prediction, append, gradients)
+    if (tid < d) par_dev[tid] = par.invlam[tid];
+    if (tid == 0) {
+        par_dev[d] = par.amp2;
+        par_dev[d + 1] = par.sig2;
+    }
+    for (int idx = tid; idx < d * Np; idx += DIAG_THREADS) {
+        const int k = idx / Np, j = idx - k * Np;
+        const double v = Xraw[idx] * par.invlam[k];          // ARDTransform(1 ./ λ), gaussian_process.jl:243
+        Xsc[idx] = v;
+        if (j < SMALL_MAX_N) xs[k * SMALL_MAX_N + j] = v;
+    }
+    if (tid < SMALL_MAX_N) rhs[tid] = (tid < N) ? y[tid] - mean[tid] : 0.0;
+    __syncthreads();
+    // Gram tiles K = α² κ(r) + σ² I, padding rows / columns of the last panel = identity
+    const int ntl = nsub * (nsub + 1) / 2;
+    for (int idx = tid; idx < ntl * 256; idx += DIAG_THREADS) {
+        const int tl = idx >> 8, e = idx & 255;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
+        const int tj = tl - ti * (ti + 1) / 2;
+        const int r = e & 15, c = e >> 4, i = ti * 16 + r, j = tj * 16 + c;
+        double v = 0.0;
+        if (i >= j) {
+            if (i < N && j < N) {
+                double r2 = 0.0;
+                for (int k = 0; k < d; ++k) {
+                    const double diff = xs[k * SMALL_MAX_N + i] - xs[k * SMALL_MAX_N + j];
+                    r2 = __builtin_fma(diff, diff, r2);
+                }
+                v = par.amp2 * kappa_r2(par.kern, r2) + ((i == j) ? par.sig2 : 0.0);
+            } else {
+                v = (i == j) ? 1.0 : 0.0;
+            }
+        }
+        smem[tl * 256 + c * 16 + r] = v;
+    }
+    __syncthreads();
+    int fail = -1;
+    diag_block_factor<true>(smem, A, ld, inv16, 0, nsub, fail, Is);
+    __syncthreads();
+    if (wv == 0) {
+        // z = L \ (y - m), tile by tile: z_jb = inv(L16_jb) (δ_jb − Σ_{m<jb} L(jb, m) z_m); lane l carries the running sums of
+        // rows l and l + 64
+        const int r16 = lane & 15, q = lane >> 4;
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int jb = 0; jb < nsub; ++jb) {
+            // v = δ_jb − acc_jb
+            const int row0 = 16 * jb;
+            if (lane >= (row0 & 63) && lane < (row0 & 63) + 16) rhs[row0 + (lane - (row0 & 63))] -= (row0 < 64) ? acc0 : acc1;
+            // z(r) = Σ_c X(r, c) v(c),  X(r, c) at c*16 + r: lane (r16, q) sums c = q, q+4, q+8, q+12, then the four quarters add up
+            double zs = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = q + 4 * i;
+                zs = __builtin_fma(Is[jb * 256 + c * 16 + r16], rhs[row0 + c], zs);
+            }
+            zs += __shfl_xor(zs, 16);
+            zs += __shfl_xor(zs, 32);
+            if (q == 0) rhs[SMALL_MAX_N + row0 + r16] = zs;                       // z lives behind the right-hand side
+            // acc(row) += Σ_c L(row, 16jb + c) z(c) for the rows below this panel
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = lane + 64 * h, ti = row >> 4;
+                if (ti > jb && ti < nsub) {
+                    const double* Lt = smem + dtile(ti, jb) + (row & 15);
+                    double a = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) a = __builtin_fma(Lt[c * 16], rhs[SMALL_MAX_N + row0 + c], a);
+                    if (h == 0) acc0 += a;
+                    else acc1 += a;
+                }
+            }
+        }
+        // logdet = 2 Σ log L_ii, zz = Σ z_i²  (i < N)
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = lane + 64 * h;
+            if (i < N) {
+                s0 += log(smem[dtile(i >> 4, i >> 4) + (i & 15) * 17]);
+                const double z = rhs[SMALL_MAX_N + i];
+                s1 = __builtin_fma(z, z, s1);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_xor(s0, off);
+            s1 += __shfl_xor(s1, off);
+        }
+        if (lane == 0) {
+            const int inf = fail >= 0 ? fail + 1 : 0;
+            scal[0] = 2.0 * s0;
+            scal[1] = s1;
+            info[0] = inf;
+            host_res[0] = 2.0 * s0;
+            host_res[1] = s1;
+            reinterpret_cast<int*>(host_res + 2)[0] = inf;
+        }
+    }
+    __syncthreads();
+    // factor tiles (diagonal ones included, zero above the diagonal) and the z row
+    for (int tl = wv; tl < ntl; tl += DIAG_THREADS / 64) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
+        const int tj = tl - ti * (ti + 1) / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
+            *reinterpret_cast<v2d*>(A + (size_t)(tj * 16 + c) * ld + ti * 16 + 2 * rp) =
+                *reinterpret_cast<const v2d*>(smem + tl * 256 + c * 16 + 2 * rp);
+        }
+    }
+    for (int c = tid; c < Np; c += DIAG_THREADS) {
+        A[(size_t)c * ld + Np] = (c < 16 * nsub) ? rhs[SMALL_MAX_N + c] : 0.0;
+        if (c >= 16 * nsub) A[(size_t)c * ld + c] = 1.0;                          // identity padding of the factor
+    }
+    // identity inverses of the padding panels (the panel solves of an append and the block inverses read them)
+    const int npan = Np / 16;
+    for (int idx = tid; idx < (npan - nsub) * 256; idx += DIAG_THREADS) {
+        const int pnl = nsub + (idx >> 8), e = idx & 255;
+        inv16[pnl * 256 + e] = ((e & 15) == (e >> 4)) ? 1.0 : 0.0;
     }
 }
 
@@ -377,7 +620,9 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k,
 //                       panel (first = k+2) — runs on the side stream, 128×128 tiles;
 //   potrf_colupd_kernel only block column k+1 (the next panel), 32×128 tiles so that this short
 //                       kernel on the critical path is one small round.
-template <int NPAN>
+typedef GemmDirect<2, 2, 2, 4, 4> SyrkHalfG;   // 64×128 half tile: workgroups half as long (look-ahead: the chain's kernels get CUs sooner)
+
+template <int NPAN, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
                                                             int first, int m, int batch1d) {
     constexpr int npan = NPAN;                              // compile-time K keeps the tile loop inside the register budget
@@ -402,8 +647,10 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
         while ((i + 1) * (i + 2) / 2 <= t) ++i;
         while (i * (i + 1) / 2 > t) --i;
         int j = t - i * (i + 1) / 2;
-        syrk_tile<SyrkG>(A, ld, k, (first + i) * BLK, (first + j) * BLK, npan * BLK);
+        if constexpr (HALF) syrk_tile<SyrkHalfG>(A, ld, k, (first + i) * BLK + 64 * blockIdx.y, (first + j) * BLK, npan * BLK);
+        else syrk_tile<SyrkG>(A, ld, k, (first + i) * BLK, (first + j) * BLK, npan * BLK);
     } else {
+        if (HALF && blockIdx.y != 0) return;
         int j = t - nsq;
         syrk_tile<RhsG>(A, ld, k, (first + m) * BLK, (first + j) * BLK, npan * BLK);
     }

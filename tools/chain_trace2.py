@@ -16,16 +16,16 @@ def build():
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
     p = os.path.join(tmp, "boss.jl_amd", "csrc", "potrf.hpp")
     s = open(p).read()
-    s = s.replace("constexpr int DIAG_THREADS = 1024;",
+    s = s.replace("constexpr int DIAG_TILES = 36;",
                   "__device__ unsigned long long g_t0[8 * 64], g_t1[8 * 64];\n__device__ unsigned int g_cu[2 * 8 * 4 * 16];\n"
                   "#define TR_BEGIN(code, kk) const int tr_i_ = (code) * 64 + ((kk) & 63); if (threadIdx.x == 0 && blockIdx.z == 0) "
                   "{ atomicMin(&g_t0[tr_i_], (unsigned long long)__builtin_amdgcn_s_memrealtime()); unsigned xc_, hw_; "
                   "asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xc_)); asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw_)); "
                   "atomicAdd(&g_cu[((((code) == 4 ? 1 : 0) * 8 + (xc_ & 7)) * 4 + ((hw_ >> 13) & 3)) * 16 + ((hw_ >> 8) & 15)], 1u); }\n"
                   "#define TR_END() if (threadIdx.x == 0 && blockIdx.z == 0) atomicMax(&g_t1[tr_i_], (unsigned long long)__builtin_amdgcn_s_memrealtime());\n"
-                  "constexpr int DIAG_THREADS = 1024;", 1)
-    s = s.replace("    extern __shared__ double smem[];\n    double* D = smem;", "    TR_BEGIN(1, k);\n    extern __shared__ double smem[];\n    double* D = smem;", 1)
-    i = s.index("    // ---- write L: 16-byte stores")
+                  "constexpr int DIAG_TILES = 36;", 1)
+    s = s.replace("    extern __shared__ double smem[];\n    const int tid = threadIdx.x;", "    TR_BEGIN(1, k);\n    extern __shared__ double smem[];\n    const int tid = threadIdx.x;", 1)
+    i = s.index("    // ---- write L: the tiles strictly below")
     j = s.index("\n}\n", i)
     s = s[:j] + "\n    __syncthreads();\n    TR_END();" + s[j:]
     for code, head in (("(row0 == (k + 1) * BLK && gridDim.x == 8) ? 5 : 2", "__global__ __launch_bounds__(64) void potrf_trsm_kernel("),

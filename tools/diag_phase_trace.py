@@ -16,14 +16,14 @@ def build():
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
     p = os.path.join(tmp, "boss.jl_amd", "csrc", "potrf.hpp")
     s = open(p).read()
-    s = s.replace("constexpr int DIAG_THREADS = 1024;",
+    s = s.replace("constexpr int DIAG_TILES = 36;",
                   "__device__ unsigned long long g_ph[64 * 8 * 8];\n"
-                  "#define PH(slot) do { if (lane == 0 && blockIdx.z == 0 && k < 64) { unsigned long long t_; "
-                  "asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t_) :: \"memory\"); g_ph[(k * 8 + jb) * 8 + (slot)] = t_; } } while (0)\n"
-                  "constexpr int DIAG_THREADS = 1024;", 1)
-    s = s.replace("        if (wave == 0) {\n            v4d E;\n            chol16_with_inverse(S, E, lane, k * BLK + jb * 16, fail);",
-                  "        if (wave == 0) {\n            v4d E;\n            PH(0);\n            chol16_with_inverse(S, E, lane, k * BLK + jb * 16, fail);\n            PH(1);", 1)
-    s = s.replace("        lds_barrier();                                // barrier 1: L16/E published, block fully updated through panel jb-1",
+                  "#define PH(slot) do { if (lane == 0 && blockIdx.z == 0 && col0 / 128 < 64) { unsigned long long t_; "
+                  "asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t_) :: \"memory\"); g_ph[(col0 / 128 * 8 + jb) * 8 + (slot)] = t_; } } while (0)\n"
+                  "constexpr int DIAG_TILES = 36;", 1)
+    s = s.replace("        if (wave == 0) {\n            v4d E;\n            chol16_unscaled(S, E, ipsel, lane, col0 + jb * 16, fail);",
+                  "        if (wave == 0) {\n            v4d E;\n            PH(0);\n            chol16_unscaled(S, E, ipsel, lane, col0 + jb * 16, fail);\n            PH(1);", 1)
+    s = s.replace("        lds_barrier();                                // barrier 1: S'/E' published, block fully updated through panel jb-1",
                   "        if (wave == 1) PH(5);\n        lds_barrier();                                // barrier 1\n        if (wave == 0) PH(2);", 1)
     s = s.replace("        lds_barrier();                                // barrier 2: panel jb final",
                   "        if (wave == 0) PH(3);\n        lds_barrier();                                // barrier 2\n        if (wave == 0) PH(4);", 1)
