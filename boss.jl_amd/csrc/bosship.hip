@@ -73,10 +73,7 @@ struct Ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // trailing updates of the look-ahead Cholesky
-    hipStream_t mid_stream = nullptr;           // split chain: the panel rows / column strips that are not on the critical path
-    hipStream_t chain_stream = nullptr;         // CU-partitioned look-ahead: the panel chain on the CUs the bulk stream's mask leaves out
     std::vector<hipEvent_t> ev_panel, ev_rest;  // per-step dependency events (no timing)
-    std::vector<hipEvent_t> ev_diag, ev_next, ev_mid;   // split chain: diagonal block done / first block row solved / rest of the step done
     hipEvent_t ev_fork = nullptr, ev_up = nullptr;            // ev_up: last upload out of the pinned staging area
     bool lookahead = true;
     bool prof_on = false;
@@ -101,8 +98,6 @@ static void ctx_destroy(Ctx* c) {
     if (!c) return;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    if (c->mid_stream) (void)hipStreamDestroy(c->mid_stream);
-    if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     for (int i = 0; i < Ctx::LLG_BANKS - 1; ++i) {
@@ -120,60 +115,7 @@ static int ctx_init(Ctx* c) {
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest));
         c->stream = c->own_stream;
-        // CU partition for the look-ahead factorisation.  The bulk trailing updates' 128×128 tiles fill the register files of
-        // the CUs they run on for tens of microseconds, and the workgroup dispatcher does not steer a chain kernel's workgroups
-        // towards idle CUs: they are dealt over all CUs and wait for "their" CU (device timeline with a bulk-only mask,
-        // profiles/r02_cu_partition.log: 36 CUs never ran a bulk workgroup, yet only 17 % of the chain workgroups landed there and the
-        // solve / column-update kernels were as slow as without a mask: 30 µs instead of 9).  So BOTH sides get a mask: the
-        // panel chain runs on a stream restricted to the reserved CUs, the bulk on the complement.  The mask bits below enable
-        // the same (shader engine, CU) position in each of the 8 XCDs (tools/cumask_probe.hip on MI355X, ROCm 7.2) — workgroups
-        // are dealt round-robin over the XCDs, so every XCD must keep its share; on another part the two masks are still
-        // complementary (correct, possibly unevenly spread).  BOSS_BULK_RESERVE=0 turns the partition off.
-        // Measured (profiles/r02_cu_partition.log): with 64 CUs for the chain the solve / column-update kernels no longer stall
-        // behind bulk tiles, but they run on a quarter of the machine (14 + 12 µs instead of 9 + 7, the two-column K = 256
-        // update 33 µs instead of 13) and the bulk needs a second round of tiles on its 192 CUs (120 µs instead of 79):
-        // 1.82 ms against 1.71 ms at N = 4096 — off by default (BOSS_BULK_RESERVE=64 turns it on).
-        static const int reserve = getenv("BOSS_BULK_RESERVE") ? atoi(getenv("BOSS_BULK_RESERVE")) : 0;
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, c->device));
-        const int ncu = prop.multiProcessorCount;
-        bool masked = false;
-        if (reserve > 0 && ncu == 256) {
-            static const int groups[16][9] = {{0, 30, 62, 90, 117, 145, 175, 203, 228},    // se0 cu0
-                                              {4, 8, 69, 97, 127, 155, 182, 210, 236},     // se1 cu1
-                                              {10, 16, 78, 106, 135, 163, 189, 217, 244},  // se2 cu0
-                                              {23, 24, 87, 115, 141, 169, 198, 226, 252},  // se3 cu1
-                                              {26, 58, 85, 113, 143, 171, 196, 224, -1},   // se0 cu7
-                                              {37, 65, 95, 123, 150, 178, 204, 232, -1},   // se1 cu8
-                                              {6, 46, 74, 103, 131, 157, 185, 212, 240},   // se2 cu7
-                                              {19, 55, 83, 109, 137, 166, 194, 220, 248},  // se3 cu8
-                                              {15, 47, 75, 100, 128, 190, 218, 245, -1},   // se0 cu4
-                                              {22, 50, 76, 104, 165, 193, 223, 251, -1},   // se1 cu4
-                                              {35, 61, 89, 116, 144, 206, 234, -1, -1},    // se2 cu4
-                                              {1, 38, 66, 92, 120, 183, 211, 237, -1},     // se3 cu4
-                                              {7, 36, 64, 126, 154, 181, 209, 239, -1},    // se0 cu2
-                                              {12, 40, 101, 129, 159, 187, 214, 242, -1},  // se1 cu2
-                                              {25, 52, 80, 142, 170, 199, 227, 253, -1},   // se2 cu2
-                                              {28, 56, 119, 147, 173, 201, 230, -1, -1}};  // se3 cu2
-            std::vector<uint32_t> bulk((ncu + 31) / 32, 0xffffffffu), chain((ncu + 31) / 32, 0u);
-            const int ng = std::min(16, std::max(4, reserve / 8));
-            for (int gi = 0; gi < ng; ++gi)
-                for (int b : groups[gi])
-                    if (b >= 0) {
-                        bulk[b / 32] &= ~(1u << (b % 32));
-                        chain[b / 32] |= 1u << (b % 32);
-                    }
-            masked = hipExtStreamCreateWithCUMask(&c->side_stream, (uint32_t)bulk.size(), bulk.data()) == hipSuccess &&
-                     hipExtStreamCreateWithCUMask(&c->chain_stream, (uint32_t)chain.size(), chain.data()) == hipSuccess;
-            if (!masked) {
-                (void)hipGetLastError();
-                if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-                if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
-                c->side_stream = c->chain_stream = nullptr;
-            }
-        }
-        if (!masked) HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
-        HIPCHK(hipStreamCreateWithPriority(&c->mid_stream, hipStreamNonBlocking, (least + greatest) / 2));
+        HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
@@ -186,8 +128,6 @@ static int ctx_init(Ctx* c) {
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -657,15 +657,13 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
 }
 
 __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                              int m, int ncols, int jfirst, int npan, int tskip = 0) {
+                                                              int m, int ncols, int jfirst, int npan) {
     // npan = 2: apply the TWO panels k-1, k (K = 256) — the odd steps of the paired look-ahead schedule
     // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
     // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
     // (used for the last steps, where one small launch beats the two-stream choreography).
-    // tskip: leave out the first tskip strips (4 = the diagonal block of the first column handled: the split chain
-    // updates that block with potrf_diagupd_kernel on the critical path and the rest of the column here, off it)
     double* A = Abase + (size_t)blockIdx.z * bstride;
-    int t = blockIdx.x + tskip;
+    int t = blockIdx.x;
     int j = jfirst;                                           // first trailing block column handled (0 = column k+1)
     if (ncols > 1) {
         // column j has 4*(m-j)+1 strips
@@ -678,60 +676,6 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     const int R0 = (t < nstr) ? (k + 1 + j) * BLK + t * 32 : (k + 1 + m) * BLK;
     if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, R0, (k + 1 + j) * BLK, 2 * BLK);
     else syrk_tile<RhsG>(A, ld, k, R0, (k + 1 + j) * BLK);
-}
-
-// The diagonal block the next step factorises, brought up to date on the critical path:
-//   A[k+1,k+1] -= P[k+1,k] P[k+1,k]^T            (npan = 1)
-//   A[k+1,k+1] -= P[k+1,k-1] P[k+1,k-1]^T + P[k+1,k] P[k+1,k]^T   (npan = 2, the odd steps of the paired schedule)
-// Ten workgroups, one per 32×32 block of the lower block triangle; the contraction is split over the four waves
-// (each wave a quarter of the K = 128·npan columns, 8·npan dependent MFMAs per tile instead of 32·npan), partial
-// tiles summed through LDS in a fixed order.  A kernel of ≈2 µs between the panel's first solve and the next diagonal block.
-__global__ __launch_bounds__(256) void potrf_diagupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k, int npan) {
-    __shared__ double part[4][4][4][64];                      // [wave][tile][reg][lane]
-    double* A = Abase + (size_t)blockIdx.z * bstride;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, q = lane >> 4;
-    int bi = 0, b = blockIdx.x;                               // block (bi, bj), bi >= bj, of the 4×4 grid of 32×32 blocks
-    while (b > bi) {
-        b -= bi + 1;
-        ++bi;
-    }
-    const int bj = b;
-    const int r0 = (k + 1) * BLK;
-    const int kcols = BLK * npan / 4;                         // this wave's share of the contraction
-    const double* P = A + (size_t)((k + 1 - npan) * BLK + wave * kcols) * ld + r0;   // P(r, c) = P[r + c*ld], columns of this wave
-    v4d acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[a][c] = v4d{0.0, 0.0, 0.0, 0.0};
-    for (int s4 = 0; s4 < kcols / 4; ++s4) {
-        const double* Pk = P + (size_t)(4 * s4 + q) * ld;
-        double fi[2], fj[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            fi[a] = Pk[32 * bi + 16 * a + r16];               // B operand [k][y = row of C]
-            fj[a] = Pk[32 * bj + 16 * a + r16];               // A operand [x = column of C][k]
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[a][c] = mfma_f64(-fj[c], fi[a], acc[a][c]);
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) part[wave][2 * a + c][i][lane] = acc[a][c][i];
-    __syncthreads();
-    // wave w finishes tile w = (a, c): C(row = 32bi + 16a + r16, col = 32bj + 16c + q + 4i)
-    const int a = wave >> 1, c = wave & 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        double* dst = A + (size_t)(r0 + 32 * bj + 16 * c + q + 4 * i) * ld + r0 + 32 * bi + 16 * a + r16;
-        *dst += ((part[0][wave][i][lane] + part[1][wave][i][lane]) + part[2][wave][i][lane]) + part[3][wave][i][lane];
-    }
 }
 
 // Block-row variant for boss_gp_append: behind panel k update ONLY block row kb (4 strips of

@@ -32,6 +32,8 @@ def build():
                        (3, "__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel("),
                        (6, "__global__ __launch_bounds__(256) void potrf_diagupd_kernel("),
                        (4, "__global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(")):
+        if head not in s:
+            continue
         i = s.index(head)
         kpos = s.index("{\n", i) + 2
         s = s[:kpos] + f"    TR_BEGIN({code}, k);\n" + s[kpos:]
