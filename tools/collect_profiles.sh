@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence for bench.py (run on the GPU box from the repo root):
+#   1. kernel trace + stats of the default bench command           -> profiles/<tag>_bench_kernel_stats.csv
+#   2. separate --pmc passes for FETCH_SIZE and WRITE_SIZE           -> profiles/<tag>_pmc_summary.json (carries the source hash)
+# usage: bash tools/collect_profiles.sh r02_v3
+set -e
+tag=${1:-r02}
+out=gpurun_out/prof_$tag
+mkdir -p $out profiles
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/bench_stats.json 2> $out/stats.err
+cp $(find $out/stats -name "s_kernel_stats.csv" | head -1) profiles/${tag}_bench_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -o f -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $out/bench_f.json 2> $out/f.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -o w -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $out/bench_w.json 2> $out/w.err
+python3 tools/pmc_summary.py $(find $out/pmc_f -name "f_counter_collection.csv" | head -1) $(find $out/pmc_w -name "w_counter_collection.csv" | head -1) profiles/${tag}_pmc_summary.json
+cp profiles/${tag}_pmc_summary.json gpurun_out/
+cp profiles/${tag}_bench_kernel_stats.csv gpurun_out/
+echo "profiles written for $tag"
