@@ -527,6 +527,7 @@ __global__ __launch_bounds__(64) void potrf_trsm_kernel(double* __restrict__ Aba
                                                         size_t inv16_bstride, int row0) {
     // row0: first row solved by 16-row group 0 — (k+1)*BLK in the factorisation (everything below
     // the diagonal block); boss_gp_append solves only the block row it rebuilds, or only the δ^T rows
+    __builtin_amdgcn_s_setprio(3);           // a chain kernel: its waves win issue arbitration over co-resident bulk-update waves
     const int lane = threadIdx.x;
     double* A = Abase + (size_t)blockIdx.z * bstride;
     const double* Lkk = A + (size_t)k * BLK * ((size_t)ld + 1);
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
     // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
     // (used for the last steps, where one small launch beats the two-stream choreography).
+    __builtin_amdgcn_s_setprio(3);           // a chain kernel: its waves win issue arbitration over co-resident bulk-update waves
     double* A = Abase + (size_t)blockIdx.z * bstride;
     int t = blockIdx.x;
     int j = jfirst;                                           // first trailing block column handled (0 = column k+1)

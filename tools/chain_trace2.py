@@ -69,7 +69,7 @@ if __name__ == "__main__":
         print("built", build())
         sys.exit(0)
     from boss_jl_amd import api
-    lib = api.load_library(os.path.join(ROOT, "tools", "libbosship_t2.so"))
+    lib = api.load_library(os.path.join(ROOT, "tools", os.environ.get("BOSS_T2_LIB", "libbosship_t2.so")))
     lib.boss_debug_trace2.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     rng = np.random.default_rng(0)
