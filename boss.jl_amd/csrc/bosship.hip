@@ -75,6 +75,13 @@ struct Ctx {
     hipStream_t side_stream = nullptr;          // trailing updates of the look-ahead Cholesky
     std::vector<hipEvent_t> ev_panel, ev_rest;  // per-step dependency events (no timing)
     hipEvent_t ev_fork = nullptr, ev_up = nullptr;            // ev_up: last upload out of the pinned staging area
+    // Cross-stream release without an event: a chain kernel stores the next sequence number here at its entry, and a
+    // one-wave gate kernel in front of the bulk update on the side stream polls the word (sleeping between polls) and
+    // exits when it is reached.  An event costs the recording stream 3 µs and reaches the waiting stream after 11-13 µs;
+    // hipStreamWaitValue64 is fast (2.6 µs) but its polling wave slows whatever shares its SIMD by 2x
+    // (tools/streamwait_probe.hip, profiles/r02_chain_timeline_waitvalue.log).  nullptr (BOSS_NO_GATE=1): events.
+    unsigned long long* sig_panel = nullptr;
+    unsigned long long sig_seq = 0;
     bool lookahead = true;
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
@@ -99,6 +106,7 @@ static void ctx_destroy(Ctx* c) {
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->sig_panel) (void)hipFree(c->sig_panel);
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     for (int i = 0; i < Ctx::LLG_BANKS - 1; ++i) {
         if (c->llg_stream[i]) (void)hipStreamDestroy(c->llg_stream[i]);
@@ -124,6 +132,13 @@ static int ctx_init(Ctx* c) {
         HIPCHK(hipEventCreateWithFlags(&c->llg_join[i], hipEventDisableTiming));
     }
     c->lookahead = !(getenv("BOSS_NO_LOOKAHEAD") && atoi(getenv("BOSS_NO_LOOKAHEAD")));
+    {
+        static const bool gate_off = getenv("BOSS_NO_GATE") && atoi(getenv("BOSS_NO_GATE"));
+        if (!gate_off) {
+            HIPCHK(hipMalloc((void**)&c->sig_panel, 64));
+            HIPCHK(hipMemset(c->sig_panel, 0, 64));
+        }
+    }
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));

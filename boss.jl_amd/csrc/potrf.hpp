@@ -293,11 +293,30 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
     }
 }
 
+// Gate in front of a kernel on another stream: one lane polls a sequence word until it reaches v (the producer stream's
+// next kernel stores it at its entry, see potrf_diag_kernel), sleeping ≈0.4 µs between polls so that it does not disturb the
+// waves it shares a SIMD with.  The spin is bounded (≈1 s); a timeout marks the factorisation as failed (info = INT_MIN)
+// instead of letting the gated kernel run on unfinished operands.
+__global__ __launch_bounds__(64) void potrf_gate_kernel(unsigned long long* __restrict__ sig, unsigned long long v,
+                                                        int* __restrict__ info) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < (1 << 21); ++i) {
+        if (__hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    info[0] = INT_MIN;
+}
+
+// sig / sigval: when sig is non-null the kernel stores sigval there at its entry — every earlier kernel of its stream has
+// finished by then, so a gate kernel on another stream can release work that depends on them (the look-ahead
+// schedule's bulk update) without an event on this stream.
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ Abase, int ld, size_t bstride,
                                                                   int k, double* __restrict__ inv16base,
-                                                                  size_t inv16_bstride, int* __restrict__ info) {
+                                                                  size_t inv16_bstride, int* __restrict__ info,
+                                                                  unsigned long long* sig, unsigned long long sigval) {
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
+    if (sig && tid == 0 && blockIdx.z == 0) __hip_atomic_store(sig, sigval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double* A = Abase + (size_t)blockIdx.z * bstride + (size_t)k * BLK * ((size_t)ld + 1);
     double* inv16 = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
     // lower tiles global -> LDS, a wave per tile (36 tiles over 16 waves), 16-byte accesses: lane l moves the pairs l and l + 64
