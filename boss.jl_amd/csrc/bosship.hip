@@ -245,7 +245,8 @@ struct boss_gp {
     bool has_mean = false, fitted = false, pending = false, have_dinv = false;
     bool dinv_used = false;                    // the current block inverses were used by a prediction (see factor_enqueue)
     double* host_res = nullptr;                // pinned: scal[2], info
-    double* host_res_dev = nullptr;            // the same memory through its device address (written by small_fit_kernel)
+    double* host_res_dev = nullptr;            // the same memory through its device address (written by small_fit_kernel / potrf_logdet_kernel)
+    bool par_in_args = false;                  // this update's hyper-parameters travel in the first kernel's arguments
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
     unsigned long long epoch = 0;              // bumped by every boss_gp_update: tracked candidate states go stale

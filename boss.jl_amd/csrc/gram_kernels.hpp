@@ -19,6 +19,23 @@ __global__ void scale_points_kernel(const double* __restrict__ Xraw, double* __r
     for (int k = 0; k < d; ++k) Xsc[(size_t)b * xs_bstride + (size_t)k * ldp + j] = Xraw[(size_t)k * ldp + j] * invlam[b * d + k];
 }
 
+// The same for one posterior whose hyper-parameters travel in the kernel arguments (no staging copy, no event): the kernel
+// also deposits 1/λ, α², σ² in the handle's resident parameter block (invlam[0..d), then hyp[0..2)) for the kernels that follow.
+constexpr int HYP_ARGS_MAX_D = 32;
+struct HypArgs {
+    int d;
+    double invlam[HYP_ARGS_MAX_D];
+    double hyp[2];
+};
+__global__ void scale_points_args_kernel(HypArgs par, const double* __restrict__ Xraw, double* __restrict__ Xsc,
+                                         double* __restrict__ par_dev, int ldp) {
+    if (blockIdx.x == 0 && threadIdx.x < par.d + 2)
+        par_dev[threadIdx.x] = threadIdx.x < par.d ? par.invlam[threadIdx.x] : par.hyp[threadIdx.x - par.d];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldp) return;
+    for (int k = 0; k < par.d; ++k) Xsc[(size_t)k * ldp + j] = Xraw[(size_t)k * ldp + j] * par.invlam[k];
+}
+
 // RHS row block: row Np = (y - m)^T for j < N, everything else in rows Np..Np+31 zero.
 // col0: first column to (re)write — 0 for a full fit, the first column of the re-factorised block
 // row for boss_gp_append (the z entries of the columns before it are final and must survive).

@@ -711,8 +711,13 @@ __global__ __launch_bounds__(256, 2) void potrf_rowupd_kernel(double* __restrict
 
 // logdet = 2 Σ_{i<N} log L_ii ,  zz = Σ_{j<N} z_j²   →  scal[2*b], scal[2*b+1]
 constexpr int LOGDET_THREADS = 1024;                          // at the end of the chain: every thread takes N/1024 diagonal entries
+// host_out (or null; single matrix): mapped host memory that receives {logdet, zᵀz, info} directly — the update then ends
+// with this kernel instead of a device-to-host copy behind it.  sig / sigval: as in potrf_diag_kernel.
 __global__ __launch_bounds__(LOGDET_THREADS) void potrf_logdet_kernel(const double* __restrict__ Abase, int ld, size_t bstride,
-                                                                      int N, int Np, double* __restrict__ scal) {
+                                                                      int N, int Np, double* __restrict__ scal,
+                                                                      double* __restrict__ host_out, const int* __restrict__ info,
+                                                                      unsigned long long* sig, unsigned long long sigval) {
+    if (sig && threadIdx.x == 0 && blockIdx.z == 0) __hip_atomic_store(sig, sigval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double* A = Abase + (size_t)blockIdx.z * bstride;
     double s0 = 0.0, s1 = 0.0;
     for (int i = threadIdx.x; i < N; i += LOGDET_THREADS) {
@@ -734,6 +739,11 @@ __global__ __launch_bounds__(LOGDET_THREADS) void potrf_logdet_kernel(const doub
     if (threadIdx.x == 0) {
         scal[2 * blockIdx.z] = 2.0 * r0[0];
         scal[2 * blockIdx.z + 1] = r1[0];
+        if (host_out && blockIdx.z == 0) {
+            host_out[0] = 2.0 * r0[0];
+            host_out[1] = r1[0];
+            reinterpret_cast<int*>(host_out + 2)[0] = info[0];
+        }
     }
 }
 
