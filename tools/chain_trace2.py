@@ -29,8 +29,10 @@ def build():
     i = s.index("    // ---- write L: the tiles strictly below")
     j = s.index("\n}\n", i)
     s = s[:j] + "\n    __syncthreads();\n    TR_END();" + s[j:]
-    for code, head in (("(row0 == (k + 1) * BLK && gridDim.x == 8) ? 5 : 2", "__global__ __launch_bounds__(64) void potrf_trsm_kernel("),
+    for code, head in ((2, "__global__ __launch_bounds__(64) void potrf_trsm_kernel("),
+                       ("(gridDim.x == 8) ? 5 : 2", "__global__ __launch_bounds__(64) void potrf_trsm_sync_kernel("),
                        (3, "__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel("),
+                       ("(t0 == 0) ? 6 : 3", "__global__ __launch_bounds__(256, 2) void potrf_colupd_part_kernel("),
                        (6, "__global__ __launch_bounds__(256) void potrf_diagupd_kernel("),
                        (4, "__global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(")):
         if head not in s:
@@ -107,7 +109,7 @@ if __name__ == "__main__":
     a0 = np.array(t0[:], dtype=np.float64).reshape(8, 64); a1 = np.array(t1[:], dtype=np.float64).reshape(8, 64)
     valid = a1 > 0
     base = a0[valid].min()
-    names = {1: "diag", 5: "solveA", 6: "diagupd", 2: "solve(B)", 3: "colupd(B)", 4: "bulk"}
+    names = {1: "diag", 5: "solve head", 6: "update head", 2: "solve rest", 3: "colupd rest", 4: "bulk"}
     print(f"N={N}; times in µs from the first chain kernel's entry; whole-kernel extents (earliest workgroup entry .. latest exit)")
     print(" k | " + " | ".join(f"{names[c_]:>16s}" for c_ in (1, 5, 6, 2, 3, 4)))
     nblk = (N + 255) // 256 * 2
@@ -123,9 +125,9 @@ if __name__ == "__main__":
     print("per-workgroup statistics (µs): n workgroups, mean / max duration, latest workgroup entry after the kernel's first")
     for k in range(nblk):
         row = [f"{k:2d}"]
-        for code in (2, 3, 4):
+        for code in (5, 6, 2, 3, 4):
             if valid[code, k] and nn[code, k] > 0:
-                row.append(f"{names[code]:>9s} n={int(nn[code, k]):4d} mean {ds[code, k]/nn[code, k]/100:5.1f} max {dm[code, k]/100:5.1f} last entry +{(sm[code, k]-a0[code, k])/100:5.1f}")
+                row.append(f"{names[code]:>11s} n={int(nn[code, k]):4d} mean {ds[code, k]/nn[code, k]/100:5.1f} max {dm[code, k]/100:5.1f} last entry +{(sm[code, k]-a0[code, k])/100:5.1f}")
         print(" | ".join(row))
     cu = (C.c_uint * (2 * 8 * 4 * 16))()
     lib.boss_debug_cus.argtypes = [C.POINTER(C.c_uint)]
