@@ -541,27 +541,120 @@ __device__ __forceinline__ void wave_trsm16(const double* __restrict__ Lkk, int 
     }
 }
 
-__global__ __launch_bounds__(64) void potrf_trsm_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                        const double* __restrict__ inv16base,
-                                                        size_t inv16_bstride, int row0) {
+// Panel solve, TWO waves per 16-row group.  One wave alone walks 176 MFMAs that mostly depend on each other (≈6 µs, the
+// longest stage of the panel chain after the diagonal block).  Here wave 0 solves the first TRSM_NA column tiles and hands
+// each finished tile to wave 1 through LDS (same lane mapping on both sides: the accumulator layout IS the B-operand
+// layout); wave 1 folds them into the remaining tiles as they arrive — consecutive MFMAs on different accumulators — and
+// finishes its own small triangle: ≈88 MFMA times on the critical path.  Every tile still receives its contributions in
+// ascending column order, so the result is bit-identical to the one-wave form (wave_trsm16, kept for the block inverses).
+constexpr int TRSM_NA = 5;
+constexpr int TRSM_THREADS = 128;
+typedef __attribute__((address_space(3))) int lds_int_t;
+__global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
+                                                                  const double* __restrict__ inv16base,
+                                                                  size_t inv16_bstride, int row0) {
     // row0: first row solved by 16-row group 0 — (k+1)*BLK in the factorisation (everything below
     // the diagonal block); boss_gp_append solves only the block row it rebuilds, or only the δ^T rows
     __builtin_amdgcn_s_setprio(3);           // a chain kernel: its waves win issue arbitration over co-resident bulk-update waves
-    const int lane = threadIdx.x;
+    __shared__ v4d xs[TRSM_NA][64];
+    __shared__ int ready;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* A = Abase + (size_t)blockIdx.z * bstride;
     const double* Lkk = A + (size_t)k * BLK * ((size_t)ld + 1);
     const double* inv16k = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
     double* Brow = A + (size_t)row0 + (size_t)blockIdx.x * 16 + (size_t)k * BLK * ld;
-    v4d acc[8];
+    if (threadIdx.x == 0) *(volatile lds_int_t*)&ready = 0;
+    __syncthreads();
+    // Every operand is fetched up front (one memory round trip per wave; the hand-off spins below are compiler barriers, loads
+    // left behind them would each expose their latency): lv(jb, m, s) = L(row = jb*16 + (lane&15), col = m*16 + 4s + (lane>>4)),
+    // iv(jb, s) = inv16_jb(4s + (lane>>4), lane&15).
+    auto lval = [&](int jb, int m, int s) { return Lkk[(size_t)(m * 16 + 4 * s + (lane >> 4)) * ld + jb * 16 + (lane & 15)]; };
+    auto ival = [&](int jb, int s) { return inv16k[jb * 256 + (4 * s + (lane >> 4)) * 16 + (lane & 15)]; };
+    if (wave == 0) {
+        v4d acc[TRSM_NA];
+        double lv[TRSM_NA][TRSM_NA][4], iv[TRSM_NA][4];
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
+        for (int jb = 0; jb < TRSM_NA; ++jb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[jb][i] = Brow[(lane & 15) + (size_t)(jb * 16 + (lane >> 4) + 4 * i) * ld];
-    wave_trsm16<false>(Lkk, ld, inv16k, acc, lane);
+            for (int i = 0; i < 4; ++i) acc[jb][i] = Brow[(lane & 15) + (size_t)(jb * 16 + (lane >> 4) + 4 * i) * ld];
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
+        for (int jb = 0; jb < TRSM_NA; ++jb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Brow[(lane & 15) + (size_t)(jb * 16 + (lane >> 4) + 4 * i) * ld] = acc[jb][i];
+            for (int s = 0; s < 4; ++s) iv[jb][s] = ival(jb, s);
+#pragma unroll
+            for (int m = 0; m < jb; ++m)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) lv[jb][m][s] = lval(jb, m, s);
+        }
+#pragma unroll
+        for (int jb = 0; jb < TRSM_NA; ++jb) {
+#pragma unroll
+            for (int m = 0; m < jb; ++m)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[jb] = mfma_f64(-lv[jb][m][s], acc[m][s], acc[jb]);
+            v4d nw = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) nw = mfma_f64(iv[jb][s], acc[jb][s], nw);
+            acc[jb] = nw;
+            xs[jb][lane] = nw;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile lds_int_t*)&ready = jb + 1;
+        }
+#pragma unroll
+        for (int jb = 0; jb < TRSM_NA; ++jb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Brow[(lane & 15) + (size_t)(jb * 16 + (lane >> 4) + 4 * i) * ld] = acc[jb][i];
+    } else {
+        constexpr int NB = 8 - TRSM_NA;
+        v4d acc[NB];
+        double lu[TRSM_NA][NB][4], lo[NB][NB][4], iv[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = Brow[(lane & 15) + (size_t)((TRSM_NA + j) * 16 + (lane >> 4) + 4 * i) * ld];
+#pragma unroll
+        for (int m = 0; m < TRSM_NA; ++m)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) lu[m][j][s] = lval(TRSM_NA + j, m, s);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) iv[j][s] = ival(TRSM_NA + j, s);
+#pragma unroll
+            for (int m = 0; m < j; ++m)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) lo[j][m][s] = lval(TRSM_NA + j, TRSM_NA + m, s);
+        }
+#pragma unroll
+        for (int m = 0; m < TRSM_NA; ++m) {
+#pragma unroll 1
+            for (int spin = 0; spin < (1 << 20) && *(volatile lds_int_t*)&ready <= m; ++spin) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const v4d x = xs[m][lane];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[j] = mfma_f64(-lu[m][j][s], x[s], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#pragma unroll
+            for (int m = 0; m < j; ++m)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[j] = mfma_f64(-lo[j][m][s], acc[m][s], acc[j]);
+            v4d nw = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) nw = mfma_f64(iv[j][s], acc[j][s], nw);
+            acc[j] = nw;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Brow[(lane & 15) + (size_t)((TRSM_NA + j) * 16 + (lane >> 4) + 4 * i) * ld] = acc[j][i];
+    }
 }
 
 // Dense inverses of all diagonal blocks (grid: 8 row groups × NBLK × batch), off the critical path.

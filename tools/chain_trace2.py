@@ -29,7 +29,7 @@ def build():
     i = s.index("    // ---- write L: the tiles strictly below")
     j = s.index("\n}\n", i)
     s = s[:j] + "\n    __syncthreads();\n    TR_END();" + s[j:]
-    for code, head in ((2, "__global__ __launch_bounds__(64) void potrf_trsm_kernel("),
+    for code, head in ((2, "__global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel("),
                        ("(gridDim.x == 8) ? 5 : 2", "__global__ __launch_bounds__(64) void potrf_trsm_sync_kernel("),
                        (3, "__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel("),
                        ("(t0 == 0) ? 6 : 3", "__global__ __launch_bounds__(256, 2) void potrf_colupd_part_kernel("),
@@ -41,7 +41,7 @@ def build():
         kpos = s.index("{\n", i) + 2
         s = s[:kpos] + f"    TR_BEGIN({code}, k);\n" + s[kpos:]
         j = s.index("\n}\n", kpos)
-        s = s[:j] + "\n    TR_END();" + s[j:]
+        s = s[:j] + ("\n    __syncthreads();" if "trsm" in head else "") + "\n    TR_END();" + s[j:]
     open(p, "w").write(s)
     p = os.path.join(tmp, "boss.jl_amd", "csrc", "bosship.hip")
     s = open(p).read() + '''
