@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64) void potrf_dinv_kernel(const double* __restrict
 // right-hand-side row block (i == m, only its first 32 rows are live).
 // ------------------------------------------------------------------------------------------
 #ifndef BOSS_RHS_D
-#define BOSS_RHS_D 4
+#define BOSS_RHS_D 12     // ring depth of the strip GEMM: K is short (128–256), the loop is bound by the distance between a fragment load and its use (4: 1.489, 8: 1.477, 12: 1.470, 16: 1.475 ms per N=4096 update)
 #endif
 typedef GemmDirect<2, 2, 4, 4, 4> SyrkG;   // 128×128 tile, fragments streamed from L2, no LDS
 typedef GemmDirect<1, 4, 2, 2, BOSS_RHS_D> RhsG;    // 32×128 tile for the δ^T row block and the column updates
