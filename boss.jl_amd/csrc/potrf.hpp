@@ -129,7 +129,9 @@ __device__ __forceinline__ int dtile(int i, int j) { return (i * (i + 1) / 2 + j
 // identity padding and are neither factored nor touched.
 // KEEP: the scaled diagonal tiles and their inverses additionally stay in LDS (tile slot (jb, jb), and Is + jb·256 in the
 // inv16 format) for a caller that goes on to solve with the factor inside the same kernel (small_fit_kernel).
-template <bool KEEP = false>
+// TILE0_GLOBAL: the pivot-chain wave takes diagonal tile 0 straight from global memory (the caller did not wait for the
+// workgroup's LDS fill: the chain starts while the other waves are still loading; barrier 1 of the first panel orders the fill).
+template <bool KEEP = false, bool TILE0_GLOBAL = false>
 __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, double* __restrict__ A, int ld,
                                                   double* __restrict__ inv16, int col0, int nsub, int& fail,
                                                   double* __restrict__ Is = nullptr) {
@@ -162,7 +164,14 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
     const int olp = (r16 * 4 + q) * 4;               // this lane's own four doubles of a staged tile
     if (wave == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S[i] = D[osym[i]];   // symmetric fill of diagonal tile 0 from its lower part
+        for (int i = 0; i < 4; ++i) {                    // symmetric fill of diagonal tile 0 from its lower part
+            if constexpr (TILE0_GLOBAL) {
+                const int c = q + 4 * i;
+                S[i] = (r16 >= c) ? A[(size_t)c * ld + r16] : A[(size_t)r16 * ld + c];
+            } else {
+                S[i] = D[osym[i]];
+            }
+        }
     }
     for (int jb = 0; jb < nsub; ++jb) {
         const int t = nsub - 1 - jb;                  // row tiles below the diagonal tile
@@ -290,6 +299,21 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
             for (int i = 0; i < 4; ++i) Xt[oel[i]] = pv[i];
         }
         lds_barrier();                                // barrier 2: panel jb final
+        if constexpr (TILE0_GLOBAL) {
+            // the finished row tiles of this panel leave for global memory now, from a wave that has nothing else to do (12: idle
+            // in both phases), instead of in a copy loop behind the last panel
+            if (wave == 12) {
+                for (int tr = jb + 1; tr < nsub; ++tr) {
+                    const double* src = D + dtile(tr, jb);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
+                        *reinterpret_cast<v2d*>(A + (size_t)(jb * 16 + c) * ld + tr * 16 + 2 * rp) =
+                            *reinterpret_cast<const v2d*>(src + c * 16 + 2 * rp);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -320,37 +344,28 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     double* A = Abase + (size_t)blockIdx.z * bstride + (size_t)k * BLK * ((size_t)ld + 1);
     double* inv16 = inv16base + (size_t)blockIdx.z * inv16_bstride + (size_t)k * (8 * 256);
     // lower tiles global -> LDS, a wave per tile (36 tiles over 16 waves), 16-byte accesses: lane l moves the pairs l and l + 64
+    // (wave 0 = the pivot chain takes tile (0,0) from global memory itself and starts at once; the other 15 waves fill the
+    // LDS with tiles 1..35, ordered before their first use by the first barrier inside diag_block_factor)
     const int lane = tid & 63, wv = tid >> 6;
-    for (int tl = wv; tl < DIAG_TILES; tl += DIAG_THREADS / 64) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
-        const int tj = tl - ti * (ti + 1) / 2;
+    if (wv != 0) {
+        for (int tl = wv; tl < DIAG_TILES; tl += DIAG_THREADS / 64 - 1) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
+            const int tj = tl - ti * (ti + 1) / 2;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
-            *reinterpret_cast<v2d*>(smem + tl * 256 + c * 16 + 2 * rp) =
-                *reinterpret_cast<const v2d*>(A + (size_t)(tj * 16 + c) * ld + ti * 16 + 2 * rp);
+            for (int h = 0; h < 2; ++h) {
+                const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
+                *reinterpret_cast<v2d*>(smem + tl * 256 + c * 16 + 2 * rp) =
+                    *reinterpret_cast<const v2d*>(A + (size_t)(tj * 16 + c) * ld + ti * 16 + 2 * rp);
+            }
         }
     }
-    __syncthreads();
     int fail = -1;
-    diag_block_factor(smem, A, ld, inv16, k * BLK, 8, fail);
+    diag_block_factor<false, true>(smem, A, ld, inv16, k * BLK, 8, fail);
     if (tid == 0 && fail >= 0) {
         if (info[blockIdx.z] == 0) info[blockIdx.z] = fail + 1;
     }
-    // ---- write L: the tiles strictly below the diagonal (the diagonal tiles went out from wave 15) ----
-    for (int tl = wv; tl < DIAG_TILES; tl += DIAG_THREADS / 64) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
-        const int tj = tl - ti * (ti + 1) / 2;
-        if (ti == tj) continue;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
-            *reinterpret_cast<v2d*>(A + (size_t)(tj * 16 + c) * ld + ti * 16 + 2 * rp) =
-                *reinterpret_cast<const v2d*>(smem + tl * 256 + c * 16 + 2 * rp);
-        }
-    }
+    // (the tiles below the diagonal went out panel by panel from wave 12, the diagonal tiles from wave 15)
 }
 
 // ------------------------------------------------------------------------------------------
