@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -133,7 +134,17 @@ static int ctx_init(Ctx* c) {
     }
     c->lookahead = !(getenv("BOSS_NO_LOOKAHEAD") && atoi(getenv("BOSS_NO_LOOKAHEAD")));
     {
-        static const bool gate_off = getenv("BOSS_NO_GATE") && atoi(getenv("BOSS_NO_GATE"));
+        // Gate kernels wait for a kernel of ANOTHER queue: where a tool lets only one kernel run on the device at a time
+        // (hardware-counter collection and thread trace under rocprofv3 serialise all queues) a gate would hold the device until
+        // its timeout.  Those modes announce themselves in the environment; anything else that serialises the device is caught
+        // at the first timeout (gp_finish falls back to events and repeats the update).
+        auto set_nonzero = [](const char* name) {
+            const char* v = getenv(name);
+            return v && *v && std::strcmp(v, "0") != 0;
+        };
+        static const bool gate_off = set_nonzero("BOSS_NO_GATE") || set_nonzero("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS") ||
+                                     getenv("ROCPROF_COUNTER_GROUPS") || set_nonzero("ROCPROF_ADVANCED_THREAD_TRACE") ||
+                                     getenv("ROCPROF_ATT_PARAM_SERIALIZE_ALL") || getenv("ROCP_METRICS") || set_nonzero("AMD_SERIALIZE_KERNEL");
         if (!gate_off) {
             HIPCHK(hipMalloc((void**)&c->sig_panel, 64));
             HIPCHK(hipMemset(c->sig_panel, 0, 64));

@@ -27,13 +27,21 @@ struct HypArgs {
     double invlam[HYP_ARGS_MAX_D];
     double hyp[2];
 };
+// ... and, in the same launch, the right-hand-side row block of rhs_rows_kernel (row Np = (y - m)^T, the 31 rows below zero) and the
+// cleared failed-pivot flag: the update's preparation is one kernel.
 __global__ void scale_points_args_kernel(HypArgs par, const double* __restrict__ Xraw, double* __restrict__ Xsc,
-                                         double* __restrict__ par_dev, int ldp) {
+                                         double* __restrict__ par_dev, int ldp, double* __restrict__ A, int ld, int N,
+                                         const double* __restrict__ y, const double* __restrict__ mean, int* __restrict__ info) {
     if (blockIdx.x == 0 && threadIdx.x < par.d + 2)
         par_dev[threadIdx.x] = threadIdx.x < par.d ? par.invlam[threadIdx.x] : par.hyp[threadIdx.x - par.d];
+    if (blockIdx.x == 0 && threadIdx.x == 0) info[0] = 0;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ldp) return;
     for (int k = 0; k < par.d; ++k) Xsc[(size_t)k * ldp + j] = Xraw[(size_t)k * ldp + j] * par.invlam[k];
+    double* col = A + (size_t)j * ld + ldp;                   // ldp = Np: the δ^T row block starts at row Np
+    col[0] = (j < N) ? (y[j] - mean[j]) : 0.0;
+#pragma unroll 1
+    for (int r = 1; r < 32; ++r) col[r] = 0.0;
 }
 
 // RHS row block: row Np = (y - m)^T for j < N, everything else in rows Np..Np+31 zero.

@@ -1337,6 +1337,42 @@ print("ok64")
     assert r.returncode == 0 and "ok64" in r.stdout, r.stdout + r.stderr
 
 
+def test_update_with_serialised_kernel_launches():
+    """The look-ahead factorisation releases kernels of its side stream through gate kernels that poll a word stored by a
+    LATER kernel of the main stream.  Where kernels execute one at a time in submission order (HIP_LAUNCH_BLOCKING, counter
+    collection under rocprofv3, a debugger) a gate enqueued before its producer would spin into its timeout and fail the
+    update; the gates are therefore enqueued behind their producers.  Same numbers as the concurrent run, update -> predict
+    -> update so that the block-inverse gate is exercised too."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+from boss_jl_amd import api
+rng = np.random.default_rng(11)
+d, N, M = 4, 4096, 64
+X = rng.uniform(0, 1, (d, N)); y = np.sin(2*np.pi*X).sum(0) + 0.05*rng.standard_normal(N)
+Xs = rng.uniform(0, 1, (d, M)); lam = np.full(d, 0.4)
+g = api.GP(X, y, "matern52")
+t = time.perf_counter()
+lp1 = g.update(lam, 1.0, 0.05)
+mu, var = g.predict(Xs)
+lp2 = g.update(lam, 1.0, 0.06)
+mu2, var2 = g.predict(Xs)
+print("RES", repr(lp1), repr(lp2), repr(float(mu2.sum())), repr(float(var2.sum())), time.perf_counter() - t)
+''' % ROOT
+    out = {}
+    # third run: the environment of a counter-collection pass (rocprofv3 --pmc serialises ALL queues, so that even a gate enqueued
+    # behind its producer would hold the device): the library must order its streams with events there
+    for tag, extra in (("concurrent", {}), ("serialised", {"HIP_LAUNCH_BLOCKING": "1"}), ("events", {"ROCPROF_COUNTER_COLLECTION": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "RES" in r.stdout, tag + ": " + r.stdout + r.stderr
+        out[tag] = [float(v) for v in r.stdout.split("RES")[1].split()]
+    a, b, e = out["concurrent"], out["serialised"], out["events"]
+    assert a[:4] == b[:4] == e[:4], (a, b, e)          # same kernels, same order of arithmetic: bit-identical
+    assert b[4] < 20.0 and e[4] < 20.0, (b, e)          # no gate ran into its (1 s) timeout
+
+
 # ------------------------------------------------------------------------------------------
 # SURVEY §8f4: GradientGaussianProcess — gradient observations, the n(1+d) augmented system
 # ------------------------------------------------------------------------------------------

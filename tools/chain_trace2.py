@@ -26,7 +26,7 @@ def build():
                   "atomicAdd(&g_ds[tr_i_], tr_e_ - tr_b_); atomicMax(&g_dm[tr_i_], tr_e_ - tr_b_); atomicAdd(&g_n[tr_i_], 1ull); }\n"
                   "constexpr int DIAG_TILES = 36;", 1)
     s = s.replace("    extern __shared__ double smem[];\n    const int tid = threadIdx.x;", "    TR_BEGIN(1, k);\n    extern __shared__ double smem[];\n    const int tid = threadIdx.x;", 1)
-    i = s.index("    // ---- write L: the tiles strictly below")
+    i = s.index("    // (the tiles below the diagonal went out panel by panel from wave 12")
     j = s.index("\n}\n", i)
     s = s[:j] + "\n    __syncthreads();\n    TR_END();" + s[j:]
     for code, head in ((2, "__global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel("),
