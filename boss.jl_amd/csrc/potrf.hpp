@@ -331,6 +331,30 @@ __global__ __launch_bounds__(64) void potrf_gate_kernel(unsigned long long* __re
     info[0] = INT_MIN;
 }
 
+// The opposite direction (side stream -> chain): a one-lane kernel enqueued right behind the bulk update stores the next sequence
+// number of ITS word when it starts (= the bulk update has completed and released its stores), and the chain kernel that needs
+// the updated columns polls that word at its entry — an event took 11-13 µs to get from one stream to the other, which the chain
+// started to wait for once its own kernels had become faster than the first bulk updates.
+__global__ __launch_bounds__(64) void potrf_publish_kernel(unsigned long long* __restrict__ word, unsigned long long v) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Every wave of the waiting kernel calls this before it touches the operands (wave-uniform; w == nullptr: nothing to wait for).
+// Normally the word is already there: one load.  A wave that had to wait re-acquires (its kernel started before the producer ended).
+__device__ __forceinline__ void wait_word(unsigned long long* w, unsigned long long v, int* info) {
+    if (!w) return;
+    bool ok = false, waited = false;
+    for (int i = 0; i < (1 << 21); ++i) {
+        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) {
+            ok = true;
+            break;
+        }
+        waited = true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok && (threadIdx.x & 63) == 0) info[0] = INT_MIN;
+    if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // sig / sigval: when sig is non-null the kernel stores sigval there at its entry — every earlier kernel of its stream has
 // finished by then, so a gate kernel on another stream can release work that depends on them (the look-ahead
 // schedule's bulk update) without an event on this stream.
@@ -785,7 +809,9 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
 }
 
 __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                              int m, int ncols, int jfirst, int npan) {
+                                                              int m, int ncols, int jfirst, int npan,
+                                                              unsigned long long* wword, unsigned long long wval, int* info) {
+    wait_word(wword, wval, info);                            // (look-ahead schedule: the bulk update that wrote these columns before)
     // npan = 2: apply the TWO panels k-1, k (K = 256) — the odd steps of the paired look-ahead schedule
     // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
     // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
