@@ -31,6 +31,7 @@ def build():
     s = s[:j] + "\n    __syncthreads();\n    TR_END();" + s[j:]
     for code, head in ((2, "__global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel("),
                        ("(gridDim.x == 8) ? 5 : 2", "__global__ __launch_bounds__(64) void potrf_trsm_sync_kernel("),
+                       (5, "__global__ __launch_bounds__(64) void potrf_follow_kernel("),
                        (3, "__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel("),
                        ("(t0 == 0) ? 6 : 3", "__global__ __launch_bounds__(256, 2) void potrf_colupd_part_kernel("),
                        (6, "__global__ __launch_bounds__(256) void potrf_diagupd_kernel("),
@@ -109,7 +110,7 @@ if __name__ == "__main__":
     a0 = np.array(t0[:], dtype=np.float64).reshape(8, 64); a1 = np.array(t1[:], dtype=np.float64).reshape(8, 64)
     valid = a1 > 0
     base = a0[valid].min()
-    names = {1: "diag", 5: "solve head", 6: "update head", 2: "solve rest", 3: "colupd rest", 4: "bulk"}
+    names = {1: "diag", 5: "follower", 6: "update head", 2: "solve", 3: "colupd", 4: "bulk"}
     print(f"N={N}; times in µs from the first chain kernel's entry; whole-kernel extents (earliest workgroup entry .. latest exit)")
     print(" k | " + " | ".join(f"{names[c_]:>16s}" for c_ in (1, 5, 6, 2, 3, 4)))
     nblk = (N + 255) // 256 * 2
