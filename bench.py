@@ -404,6 +404,12 @@ def main():
         for i in range(200):
             gs.update([1.5], 1.0, 0.1 + 1e-4 * (i % 7))
         extras["ms_update_N20_example_jl"] = (time.perf_counter() - t0) / 200 * 1e3
+        gs.loglike_grad()
+        t0 = time.perf_counter()
+        for i in range(200):                      # what one objective + gradient evaluation of a model fitter costs there
+            gs.update([1.5], 1.0, 0.1 + 1e-4 * (i % 7))
+            gs.loglike_grad()
+        extras["ms_update_plus_loglike_grad_N20"] = (time.perf_counter() - t0) / 200 * 1e3
         gs.close()
         # gradient observations (GradientGaussianProcess, §8f4): the n(1+d) = 36 864-row augmented system of the same
         # N=4096, d=8 data — 10.9 GB resident, 1.67e13 flops per update

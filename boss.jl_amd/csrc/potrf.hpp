@@ -696,6 +696,137 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel(double* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Gradient of the log marginal likelihood for N <= 128 observations in ONE launch (the reference's own regime: its model
+// fitters call data_loglike under AD with tens of points, src/model_fitters/optimization.jl:146-164).  The general path
+// (grad_kernels.hpp: block inverses, L⁻¹ by recursive doubling, K⁻¹ as a GEMM, tile partials, reduction — ten launches and
+// a copy) costs 0.14 ms at N = 20, six times the single-launch fit in front of it.  Here one workgroup does all of it:
+//   waves 0-7   L⁻¹ by the register-resident substitution of the block inverses (wave_trsm16<true>), tile-wise into LDS
+//   all         a = L⁻ᵀ z
+//   16 waves    K⁻¹ tile by tile with MFMAs straight into registers, and on those registers the pair sums
+//                   S_m = Σ_{i>j} (a_i a_j − K⁻¹_ij) α² h(r_ij) Δu²_ij,m ,  tr K⁻¹ ,  ‖a‖²
+// — the Σ-vector llgrad_finalize turns into ∂ℓ/∂(λ, α, σ) — written to mapped host memory.  Same sums as llgrad_tile_kernel
+// (every pair once, diagonal terms once); the order of the floating-point additions differs, the tolerance of the tests does not.
+// ------------------------------------------------------------------------------------------
+constexpr int SMALL_LLG_LDS_DOUBLES = DIAG_TILES * 256 + SMALL_MAX_D * SMALL_MAX_N + SMALL_MAX_N + 16 * (SMALL_MAX_D + 2);
+constexpr int SMALL_LLG_LDS_BYTES = SMALL_LLG_LDS_DOUBLES * 8;
+__global__ __launch_bounds__(DIAG_THREADS) void small_llgrad_kernel(const double* __restrict__ A, int ld, int Np, int N, int d,
+                                                                    int kern, double amp2, const double* __restrict__ inv16,
+                                                                    const double* __restrict__ Xsc, int ldx,
+                                                                    double* __restrict__ host_out) {
+    extern __shared__ double smem[];
+    double* Li = smem;                                   // L⁻¹, lower 16×16 tiles (i, j) at dtile(i, j), ROW-major inside: [row][col]
+    double* xs = Li + DIAG_TILES * 256;                  // scaled points [d][128]
+    double* av = xs + SMALL_MAX_D * SMALL_MAX_N;         // a = L⁻ᵀ z
+    double* red = av + SMALL_MAX_N;                      // per-wave partial sums [16][d + 2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsub = (N + 15) / 16;
+    for (int idx = tid; idx < d * SMALL_MAX_N; idx += DIAG_THREADS) {
+        const int k = idx / SMALL_MAX_N, j = idx - k * SMALL_MAX_N;
+        xs[idx] = (j < N) ? Xsc[(size_t)k * ldx + j] : 0.0;
+    }
+    if (tid >= DIAG_THREADS - SMALL_MAX_N) {             // z (row Np of the factor array) parked in `red` until a is formed
+        const int k = tid - (DIAG_THREADS - SMALL_MAX_N);
+        red[k] = (k < N) ? A[(size_t)k * ld + Np] : 0.0;
+    }
+    if (wave < 8) {
+        // rows r0..r0+15 of L⁻ᵀ (= columns of L⁻¹): P(r, c) = L⁻ᵀ(r, c), r = r0 + (l&15), c = jb·16 + (l>>4) + 4i
+        const int r0 = wave * 16;
+        v4d acc[8];
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[jb][i] = ((r0 + (lane & 15)) == (jb * 16 + (lane >> 4) + 4 * i)) ? 1.0 : 0.0;
+        if (wave < nsub) wave_trsm16<true>(A, ld, inv16, acc, lane);
+        // L⁻¹(k = c, i = r) = P(r, c) for k >= i: tile (kb = jb, ib = wave), element [k & 15][i & 15]
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            if (jb < wave || jb >= nsub || wave >= nsub) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = jb * 16 + (lane >> 4) + 4 * i, r = r0 + (lane & 15);
+                Li[dtile(jb, wave) + ((lane >> 4) + 4 * i) * 16 + (lane & 15)] = (k >= r) ? acc[jb][i] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < SMALL_MAX_N) {
+        // a_i = Σ_{k >= i} L⁻¹(k, i) z_k,  z_k in row Np of the factor array
+        const int i = tid, ib = i >> 4;
+        double s = 0.0;
+        if (i < N)
+            for (int k = i; k < N; ++k) s = __builtin_fma(Li[dtile(k >> 4, ib) + (k & 15) * 16 + (i & 15)], red[k], s);
+        av[i] = s;
+    }
+    __syncthreads();
+    double S[SMALL_MAX_D];
+#pragma unroll
+    for (int m = 0; m < SMALL_MAX_D; ++m) S[m] = 0.0;
+    double tr = 0.0, aa = 0.0;
+    const int T = nsub * (nsub + 1) / 2;
+    for (int tl = wave; tl < T; tl += DIAG_THREADS / 64) {
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= tl) ++bi;
+        const int bj = tl - bi * (bi + 1) / 2;
+        // K⁻¹(i, j) = Σ_{k >= i} L⁻¹(k, i) L⁻¹(k, j): MFMA rows M <-> i, columns N <-> j, contraction over the tiles kb >= bi
+        v4d kin = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = bi; kb < nsub; ++kb) {
+            const double* Ti = Li + dtile(kb, bi);
+            const double* Tj = Li + dtile(kb, bj);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int o = (4 * s4 + (lane >> 4)) * 16 + (lane & 15);     // element [k = 4s + (l>>4)][col = l&15]
+                kin = mfma_f64(Ti[o], Tj[o], kin);
+            }
+        }
+        // lane l, register r: K⁻¹(i = bi·16 + (l>>4) + 4r, j = bj·16 + (l&15))
+        const int j = bj * 16 + (lane & 15);
+        const double aj = av[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = bi * 16 + (lane >> 4) + 4 * r;
+            if (i >= N || j >= N || i < j) continue;
+            if (i == j) {
+                tr += kin[r];
+                aa = __builtin_fma(aj, aj, aa);
+                continue;
+            }
+            double r2 = 0.0;                               // (the differences are formed twice: 1024 threads leave no room for a second array)
+            for (int m = 0; m < d; ++m) {
+                const double df = xs[m * SMALL_MAX_N + i] - xs[m * SMALL_MAX_N + j];
+                r2 += df * df;
+            }
+            const double q = (av[i] * aj - kin[r]) * amp2 * kappa_prime_over_r_r2(kern, r2);
+#pragma unroll
+            for (int m = 0; m < SMALL_MAX_D; ++m) {
+                if (m < d) {
+                    const double df = xs[m * SMALL_MAX_N + i] - xs[m * SMALL_MAX_N + j];
+                    S[m] = __builtin_fma(q, df * df, S[m]);
+                }
+            }
+        }
+    }
+    // wave sums (fixed butterfly order), then the 16 wave partials in wave order
+    const int nv = d + 2;
+    for (int m = 0; m < nv; ++m) {
+        double v = (m == d) ? tr : aa;
+#pragma unroll
+        for (int mm = 0; mm < SMALL_MAX_D; ++mm)
+            if (mm == m) v = S[mm];
+        if (m >= d) v = (m == d) ? tr : aa;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave * (SMALL_MAX_D + 2) + m] = v;
+    }
+    __syncthreads();
+    if (tid < nv) {
+        double v = 0.0;
+        for (int w = 0; w < DIAG_THREADS / 64; ++w) v += red[w * (SMALL_MAX_D + 2) + tid];
+        host_out[tid] = v;
+    }
+}
+
 // Dense inverses of all diagonal blocks (grid: 8 row groups × NBLK × batch), off the critical path.
 __global__ __launch_bounds__(64) void potrf_dinv_kernel(const double* __restrict__ Abase, int ld, size_t bstride,
                                                         const double* __restrict__ inv16base, size_t inv16_bstride,

@@ -1095,7 +1095,8 @@ def test_tracked_candidates_follow_appends(api, O, N0, steps):
 
 
 @pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
-@pytest.mark.parametrize("d,N", [(1, 7), (3, 200), (8, 700), (17, 300), (4, 1300), (2, 2300)])
+@pytest.mark.parametrize("d,N", [(1, 7), (2, 1), (2, 3), (3, 16), (8, 20), (5, 127), (4, 128), (32, 100), (3, 200), (8, 700), (17, 300),
+                                 (4, 1300), (2, 2300)])   # N <= 128 with d <= 32: the single-launch kernel
 def test_loglike_gradient(api, O, kernel, d, N):
     """boss_gp_loglike_grad: ∂logpdf/∂(λ, α, σ) against the oracle's analytic restatement
     (itself pinned to finite differences on the CPU)."""
