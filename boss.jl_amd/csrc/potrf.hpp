@@ -407,36 +407,41 @@ struct SmallFitPar {
     double amp2, sig2;
     double invlam[SMALL_MAX_D];
 };
-constexpr int SMALL_LDS_DOUBLES = DIAG_TILES * 256 + DIAG_STAGE + 2 + 8 * 256 + SMALL_MAX_D * SMALL_MAX_N + 2 * SMALL_MAX_N + 8;
+constexpr int SMALL_LDS_DOUBLES = DIAG_TILES * 256 + DIAG_STAGE + 2 + 8 * 256 + SMALL_MAX_D * SMALL_MAX_N + 2 * SMALL_MAX_N + 8 + SMALL_MAX_D;
 constexpr int SMALL_LDS_BYTES = SMALL_LDS_DOUBLES * 8;
 
-__global__ __launch_bounds__(DIAG_THREADS) void small_fit_kernel(SmallFitPar par, const double* __restrict__ Xraw,
-                                                                 double* __restrict__ Xsc, const double* __restrict__ y,
-                                                                 const double* __restrict__ mean, double* __restrict__ A,
-                                                                 double* __restrict__ inv16, double* __restrict__ par_dev,
-                                                                 double* __restrict__ scal, int* __restrict__ info,
-                                                                 double* __restrict__ host_res) {
-    extern __shared__ double smem[];
+// The body shared by the one-handle kernel (hyper-parameters in the kernel arguments) and the batched one (S sets of
+// hyper-parameters on the same data, one workgroup per set: boss_gp_loglike_batch at the reference's own sizes).
+// ilam: 1/λ in LDS (filled by the caller, visible after the first barrier below); par_dev / host_res / mean may be null.
+__device__ __forceinline__ void small_fit_body(double* __restrict__ smem, int d, int N, int Np, int ld, int kern, double amp2,
+                                               double sig2, const double* __restrict__ ilam, const double* __restrict__ Xraw,
+                                               double* __restrict__ Xsc, const double* __restrict__ y,
+                                               const double* __restrict__ mean, double* __restrict__ A,
+                                               double* __restrict__ inv16, double* __restrict__ par_dev,
+                                               double* __restrict__ scal, int* __restrict__ info,
+                                               double* __restrict__ host_res) {
     double* Is = smem + DIAG_TILES * 256 + DIAG_STAGE + 2;   // scaled inverses of the diagonal tiles (inv16 format), 8 × 256
     double* xs = Is + 8 * 256;                               // scaled points [d][128]
     double* rhs = xs + SMALL_MAX_D * SMALL_MAX_N;            // y - m (then overwritten tile by tile with z)
     double* red = rhs + 2 * SMALL_MAX_N;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int d = par.d, N = par.N, Np = par.Np, ld = par.ld;
     const int nsub = (N + 15) / 16;
+    __syncthreads();                                         // ilam is in place
     // resident copies of the hyper-parameters for the entry points that follow (prediction, append, gradients)
-    if (tid < d) par_dev[tid] = par.invlam[tid];
-    if (tid == 0) {
-        par_dev[d] = par.amp2;
-        par_dev[d + 1] = par.sig2;
+    if (par_dev) {
+        if (tid < d) par_dev[tid] = ilam[tid];
+        if (tid == 0) {
+            par_dev[d] = amp2;
+            par_dev[d + 1] = sig2;
+        }
     }
     for (int idx = tid; idx < d * Np; idx += DIAG_THREADS) {
         const int k = idx / Np, j = idx - k * Np;
-        const double v = Xraw[idx] * par.invlam[k];          // ARDTransform(1 ./ λ), gaussian_process.jl:243
+        const double v = Xraw[idx] * ilam[k];                // ARDTransform(1 ./ λ), gaussian_process.jl:243
         Xsc[idx] = v;
         if (j < SMALL_MAX_N) xs[k * SMALL_MAX_N + j] = v;
     }
-    if (tid < SMALL_MAX_N) rhs[tid] = (tid < N) ? y[tid] - mean[tid] : 0.0;
+    if (tid < SMALL_MAX_N) rhs[tid] = (tid < N) ? y[tid] - (mean ? mean[tid] : 0.0) : 0.0;
     __syncthreads();
     // Gram tiles K = α² κ(r) + σ² I, padding rows / columns of the last panel = identity
     const int ntl = nsub * (nsub + 1) / 2;
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void small_fit_kernel(SmallFitPar par
                     const double diff = xs[k * SMALL_MAX_N + i] - xs[k * SMALL_MAX_N + j];
                     r2 = __builtin_fma(diff, diff, r2);
                 }
-                v = par.amp2 * kappa_r2(par.kern, r2) + ((i == j) ? par.sig2 : 0.0);
+                v = amp2 * kappa_r2(kern, r2) + ((i == j) ? sig2 : 0.0);
             } else {
                 v = (i == j) ? 1.0 : 0.0;
             }
@@ -519,9 +524,11 @@ __global__ __launch_bounds__(DIAG_THREADS) void small_fit_kernel(SmallFitPar par
             scal[0] = 2.0 * s0;
             scal[1] = s1;
             info[0] = inf;
-            host_res[0] = 2.0 * s0;
-            host_res[1] = s1;
-            reinterpret_cast<int*>(host_res + 2)[0] = inf;
+            if (host_res) {
+                host_res[0] = 2.0 * s0;
+                host_res[1] = s1;
+                reinterpret_cast<int*>(host_res + 2)[0] = inf;
+            }
         }
     }
     __syncthreads();
@@ -547,6 +554,38 @@ __global__ __launch_bounds__(DIAG_THREADS) void small_fit_kernel(SmallFitPar par
         const int pnl = nsub + (idx >> 8), e = idx & 255;
         inv16[pnl * 256 + e] = ((e & 15) == (e >> 4)) ? 1.0 : 0.0;
     }
+}
+
+__global__ __launch_bounds__(DIAG_THREADS) void small_fit_kernel(SmallFitPar par, const double* __restrict__ Xraw,
+                                                                 double* __restrict__ Xsc, const double* __restrict__ y,
+                                                                 const double* __restrict__ mean, double* __restrict__ A,
+                                                                 double* __restrict__ inv16, double* __restrict__ par_dev,
+                                                                 double* __restrict__ scal, int* __restrict__ info,
+                                                                 double* __restrict__ host_res) {
+    extern __shared__ double smem[];
+    double* ilam = smem + SMALL_LDS_DOUBLES - SMALL_MAX_D;
+    if (threadIdx.x < par.d) ilam[threadIdx.x] = par.invlam[threadIdx.x];
+    small_fit_body(smem, par.d, par.N, par.Np, par.ld, par.kern, par.amp2, par.sig2, ilam, Xraw, Xsc, y, mean, A, inv16, par_dev, scal,
+                   info, host_res);
+}
+
+// One workgroup per hyper-parameter set (blockIdx.x): 1/λ of set b at invlam[b·d ..], {α², σ²} at hyp[2b ..]; the sets' factor
+// arrays, scaled points, inverses, results and prior means lie at the given strides (mean: null, shared (stride 0) or per set).
+__global__ __launch_bounds__(DIAG_THREADS) void small_fit_batch_kernel(int d, int N, int Np, int ld, int kern,
+                                                                       const double* __restrict__ invlam,
+                                                                       const double* __restrict__ hyp,
+                                                                       const double* __restrict__ Xraw, double* __restrict__ Xsc,
+                                                                       size_t sX, const double* __restrict__ y,
+                                                                       const double* __restrict__ mean, size_t sMean,
+                                                                       double* __restrict__ A, size_t sA, double* __restrict__ inv16,
+                                                                       size_t sInv, double* __restrict__ scal, int* __restrict__ info) {
+    extern __shared__ double smem[];
+    const int b = blockIdx.x;
+    double* ilam = smem + SMALL_LDS_DOUBLES - SMALL_MAX_D;
+    if (threadIdx.x < d) ilam[threadIdx.x] = invlam[(size_t)b * d + threadIdx.x];
+    small_fit_body(smem, d, N, Np, ld, kern, hyp[2 * b], hyp[2 * b + 1], ilam, Xraw, Xsc + (size_t)b * sX, y,
+                   mean ? mean + (size_t)b * sMean : nullptr, A + (size_t)b * sA, inv16 + (size_t)b * sInv, nullptr, scal + 2 * b,
+                   info + b, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -710,11 +749,19 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel(double* __rest
 // ------------------------------------------------------------------------------------------
 constexpr int SMALL_LLG_LDS_DOUBLES = DIAG_TILES * 256 + SMALL_MAX_D * SMALL_MAX_N + SMALL_MAX_N + 16 * (SMALL_MAX_D + 2);
 constexpr int SMALL_LLG_LDS_BYTES = SMALL_LLG_LDS_DOUBLES * 8;
+// blockIdx.x: set of a batch — factor, inverses and scaled points at strides sA / sInv / sX, α² at amp2p[b·amp2_stride] (null: the
+// scalar argument), the Σ-vector to out + b·out_stride (one handle: mapped host memory, a batch: device memory).
 __global__ __launch_bounds__(DIAG_THREADS) void small_llgrad_kernel(const double* __restrict__ A, int ld, int Np, int N, int d,
                                                                     int kern, double amp2, const double* __restrict__ inv16,
                                                                     const double* __restrict__ Xsc, int ldx,
-                                                                    double* __restrict__ host_out) {
+                                                                    double* __restrict__ host_out, size_t sA, size_t sInv, size_t sX,
+                                                                    const double* __restrict__ amp2p, int amp2_stride, int out_stride) {
     extern __shared__ double smem[];
+    A += (size_t)blockIdx.x * sA;
+    inv16 += (size_t)blockIdx.x * sInv;
+    Xsc += (size_t)blockIdx.x * sX;
+    host_out += (size_t)blockIdx.x * out_stride;
+    if (amp2p) amp2 = amp2p[(size_t)blockIdx.x * amp2_stride];
     double* Li = smem;                                   // L⁻¹, lower 16×16 tiles (i, j) at dtile(i, j), ROW-major inside: [row][col]
     double* xs = Li + DIAG_TILES * 256;                  // scaled points [d][128]
     double* av = xs + SMALL_MAX_D * SMALL_MAX_N;         // a = L⁻ᵀ z

@@ -1799,7 +1799,7 @@ def test_rank_one_appends_on_resident_inverses(api, O, N0, count):
     g.close()
 
 
-@pytest.mark.parametrize("d,N,S", [(1, 7, 3), (3, 200, 5), (8, 700, 9), (4, 1300, 4)])
+@pytest.mark.parametrize("d,N,S", [(1, 7, 3), (3, 20, 5), (5, 128, 4), (32, 100, 3), (2, 17, 300), (3, 200, 5), (8, 700, 9), (4, 1300, 4)])   # N <= 128: one workgroup per set
 def test_batched_likelihood_gradients(api, O, d, N, S):
     """boss_gp_loglike_grad_batch: values and gradients of S hyper-parameter sets in one call (batched factorisations,
     gradient passes on shared workspaces) equal the oracle's and the single-handle entry points', with per-set means,
