@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -260,6 +261,8 @@ struct boss_gp {
     double* host_res = nullptr;                // pinned: scal[2], info
     double* host_res_dev = nullptr;            // the same memory through its device address (written by small_fit_kernel / potrf_logdet_kernel)
     bool par_in_args = false;                  // this update's hyper-parameters travel in the first kernel's arguments
+    unsigned long long res_seq = 0;            // sequence number the update's last kernel writes behind its results (host_res[3])
+    bool res_polled = false;                   // the pending update ends with such a kernel: gp_finish polls instead of synchronising
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
     unsigned long long epoch = 0;              // bumped by every boss_gp_update: tracked candidate states go stale

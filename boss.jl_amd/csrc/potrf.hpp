@@ -419,7 +419,7 @@ __device__ __forceinline__ void small_fit_body(double* __restrict__ smem, int d,
                                                const double* __restrict__ mean, double* __restrict__ A,
                                                double* __restrict__ inv16, double* __restrict__ par_dev,
                                                double* __restrict__ scal, int* __restrict__ info,
-                                               double* __restrict__ host_res) {
+                                               double* __restrict__ host_res, unsigned long long res_seq = 0) {
     double* Is = smem + DIAG_TILES * 256 + DIAG_STAGE + 2;   // scaled inverses of the diagonal tiles (inv16 format), 8 × 256
     double* xs = Is + 8 * 256;                               // scaled points [d][128]
     double* rhs = xs + SMALL_MAX_D * SMALL_MAX_N;            // y - m (then overwritten tile by tile with z)
@@ -528,6 +528,9 @@ __device__ __forceinline__ void small_fit_body(double* __restrict__ smem, int d,
                 host_res[0] = 2.0 * s0;
                 host_res[1] = s1;
                 reinterpret_cast<int*>(host_res + 2)[0] = inf;
+                // (polled by gp_finish; the factor tiles and the z row follow below — every consumer of those is stream-ordered)
+                __threadfence_system();
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_res + 3), res_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -561,12 +564,12 @@ __global__ __launch_bounds__(DIAG_THREADS) void small_fit_kernel(SmallFitPar par
                                                                  const double* __restrict__ mean, double* __restrict__ A,
                                                                  double* __restrict__ inv16, double* __restrict__ par_dev,
                                                                  double* __restrict__ scal, int* __restrict__ info,
-                                                                 double* __restrict__ host_res) {
+                                                                 double* __restrict__ host_res, unsigned long long res_seq) {
     extern __shared__ double smem[];
     double* ilam = smem + SMALL_LDS_DOUBLES - SMALL_MAX_D;
     if (threadIdx.x < par.d) ilam[threadIdx.x] = par.invlam[threadIdx.x];
     small_fit_body(smem, par.d, par.N, par.Np, par.ld, par.kern, par.amp2, par.sig2, ilam, Xraw, Xsc, y, mean, A, inv16, par_dev, scal,
-                   info, host_res);
+                   info, host_res, res_seq);
 }
 
 // One workgroup per hyper-parameter set (blockIdx.x): 1/λ of set b at invlam[b·d ..], {α², σ²} at hyp[2b ..]; the sets' factor
@@ -755,7 +758,8 @@ __global__ __launch_bounds__(DIAG_THREADS) void small_llgrad_kernel(const double
                                                                     int kern, double amp2, const double* __restrict__ inv16,
                                                                     const double* __restrict__ Xsc, int ldx,
                                                                     double* __restrict__ host_out, size_t sA, size_t sInv, size_t sX,
-                                                                    const double* __restrict__ amp2p, int amp2_stride, int out_stride) {
+                                                                    const double* __restrict__ amp2p, int amp2_stride, int out_stride,
+                                                                    unsigned long long res_seq) {
     extern __shared__ double smem[];
     A += (size_t)blockIdx.x * sA;
     inv16 += (size_t)blockIdx.x * sInv;
@@ -871,6 +875,11 @@ __global__ __launch_bounds__(DIAG_THREADS) void small_llgrad_kernel(const double
         double v = 0.0;
         for (int w = 0; w < DIAG_THREADS / 64; ++w) v += red[w * (SMALL_MAX_D + 2) + tid];
         host_out[tid] = v;
+        if (res_seq) __threadfence_system();                 // one handle: the host polls the word below (mapped memory)
+    }
+    if (res_seq) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out) - 1, res_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1028,7 +1037,8 @@ constexpr int LOGDET_THREADS = 1024;                          // at the end of t
 __global__ __launch_bounds__(LOGDET_THREADS) void potrf_logdet_kernel(const double* __restrict__ Abase, int ld, size_t bstride,
                                                                       int N, int Np, double* __restrict__ scal,
                                                                       double* __restrict__ host_out, const int* __restrict__ info,
-                                                                      unsigned long long* sig, unsigned long long sigval) {
+                                                                      unsigned long long* sig, unsigned long long sigval,
+                                                                      unsigned long long res_seq) {
     if (sig && threadIdx.x == 0 && blockIdx.z == 0) __hip_atomic_store(sig, sigval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double* A = Abase + (size_t)blockIdx.z * bstride;
     double s0 = 0.0, s1 = 0.0;
@@ -1055,6 +1065,9 @@ __global__ __launch_bounds__(LOGDET_THREADS) void potrf_logdet_kernel(const doub
             host_out[0] = 2.0 * r0[0];
             host_out[1] = r1[0];
             reinterpret_cast<int*>(host_out + 2)[0] = info[0];
+            // the host polls this word instead of waiting for the stream's completion signal (gp_finish): results first, then the number
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + 3), res_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
