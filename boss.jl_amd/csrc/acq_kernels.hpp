@@ -88,7 +88,7 @@ __global__ __launch_bounds__(ACQ_EPI_THREADS) void acq_epilogue_kernel(const dou
                                                                        const double* __restrict__ ymax_dev,
                                                                        double* __restrict__ acq_sum, int have_prev,
                                                                        double inv_s, const unsigned char* __restrict__ mask,
-                                                                       double* __restrict__ res) {
+                                                                       double* __restrict__ res, unsigned long long res_seq) {
     __shared__ double sv[ACQ_EPI_THREADS];
     __shared__ long si[ACQ_EPI_THREADS];
     constexpr long NONE = 0x7fffffffffffffffL;
@@ -119,6 +119,10 @@ __global__ __launch_bounds__(ACQ_EPI_THREADS) void acq_epilogue_kernel(const dou
     if (threadIdx.x == 0) {
         res[0] = sv[0];
         reinterpret_cast<long*>(res)[1] = si[0];
+        if (res_seq) {                                       // res is mapped host memory and the host polls this word (boss_acq_ei)
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(res) + 2, res_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -84,6 +84,7 @@ struct Ctx {
     // (tools/streamwait_probe.hip, profiles/r02_chain_timeline_waitvalue.log).  nullptr (BOSS_NO_GATE=1): events.
     unsigned long long* sig_panel = nullptr;
     unsigned long long sig_seq = 0;
+    unsigned long long acq_seq = 0;            // sequence number of the arg-max result block (boss_acq_ei polls it)
     bool lookahead = true;
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
@@ -152,6 +153,7 @@ static int ctx_init(Ctx* c) {
         }
     }
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
+    std::memset(c->pinned, 0, PINNED_UP_OFF);                              // (the polled sequence words start from a known value)
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
