@@ -932,7 +932,8 @@ def test_two_host_threads_share_a_device(api, O):
 
 
 @pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
-@pytest.mark.parametrize("d,N,M", [(1, 5, 3), (3, 130, 45), (8, 700, 100), (17, 300, 33)])
+@pytest.mark.parametrize("d,N,M", [(1, 5, 3), (2, 1, 7), (2, 20, 224), (4, 64, 1), (5, 127, 300), (32, 128, 65), (3, 100, 3000), (3, 130, 45), (8, 700, 100),
+                                   (17, 300, 33)])   # N <= 128 with d <= 32: the single-launch kernel
 def test_posterior_gradients(api, O, kernel, d, N, M):
     """boss_gp_predict_grad: mean / variance and their gradients w.r.t. the candidates
     against the oracle's analytic restatement (itself pinned to finite differences on the CPU)."""
@@ -967,9 +968,10 @@ def test_posterior_gradients(api, O, kernel, d, N, M):
     g.close()
 
 
-def test_posterior_gradients_discrete_and_ei_chain(api, O):
+@pytest.mark.parametrize("N", [200, 50])
+def test_posterior_gradients_discrete_and_ei_chain(api, O, N):
     rng = np.random.default_rng(8)
-    d, N, M = 3, 200, 50
+    d, M = 3, 50
     X = rng.uniform(0, 5, (d, N))
     y = np.cos(X).sum(0)
     disc = [True, False, False]

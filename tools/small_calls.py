@@ -22,7 +22,7 @@ for d, N in ((2, 20), (4, 100)):
         row.append(f"predict_grad {t(lambda: g.predict_grad(Xs)):.3f}")
         row.append(f"acq_ei(resident cand) {t(lambda: api.acq_ei([[g]], cand, [1.0], None, best, want_acq=False)):.3f}")
         try:
-            row.append(f"acq_ei_grad {t(lambda: api.acq_ei_grad([[g]], Xs, [1.0], None, best)):.3f}")
+            row.append(f"acq_ei_grad {t(lambda: api.acq_ei_grad([g], Xs, [1.0], None, best)):.3f}")
         except Exception as e:
             row.append(f"acq_ei_grad n/a ({type(e).__name__})")
         print("  ".join(row) + "  ms", flush=True)
