@@ -159,7 +159,8 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_llgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LLG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)small_predict_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPG_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)small_predict_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPG_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)small_predict_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
@@ -269,6 +270,7 @@ struct boss_gp {
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
     unsigned long long epoch = 0;              // bumped by every boss_gp_update: tracked candidate states go stale
+    unsigned long long dinv0_epoch = ~0ull;    // epoch at which block 0 of Dinv was built on its own (the small-N prediction kernels need nothing else)
     hipEvent_t dinv_ev = nullptr;              // the side stream finished building Dinv / Dinv2
     bool dinv_pending = false;
     // gradient-observation posterior (GradientGaussianProcess): npts points, N = npts (1 + d) observations,

@@ -899,6 +899,8 @@ constexpr int SPG_THREADS = 256, SPG_WAVES = SPG_THREADS / 64;
 constexpr int SPG_LDS_DOUBLES = SMALL_MAX_N * (SMALL_MAX_N + 1) / 2 + SMALL_MAX_D * SMALL_MAX_N + 2 * SMALL_MAX_N +
                                 SPG_WAVES * (2 * SMALL_MAX_N + SMALL_MAX_D);
 constexpr int SPG_LDS_BYTES = SPG_LDS_DOUBLES * 8;
+// GRAD = false: the moments alone (boss_gp_predict / boss_acq_ei at these sizes: scaling, K*, substitution and moments in one launch).
+template <bool GRAD>
 __global__ __launch_bounds__(SPG_THREADS) void small_predict_grad_kernel(const double* __restrict__ Dinv, const double* __restrict__ A,
                                                                          int ld, int Np, int N, int d, int kern, double amp2,
                                                                          const double* __restrict__ Xsc, int ldx,
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(SPG_THREADS) void small_predict_grad_kernel(const d
     }
     if (tid < SMALL_MAX_N) zs[tid] = (tid < N) ? A[(size_t)tid * ld + Np] : 0.0;
     __syncthreads();
-    if (tid < SMALL_MAX_N) {
+    if (GRAD && tid < SMALL_MAX_N) {
         double s = 0.0;
         if (tid < N) {
             const double* col = Lc + coff(tid);
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(SPG_THREADS) void small_predict_grad_kernel(const d
                 r2 = __builtin_fma(df, df, r2);
             }
             kv[i] = (i < N) ? amp2 * kappa_r2(kern, r2) : 0.0;
-            hv[i] = (i < N) ? amp2 * kappa_prime_over_r_r2(kern, r2) : 0.0;
+            if (GRAD) hv[i] = (i < N) ? amp2 * kappa_prime_over_r_r2(kern, r2) : 0.0;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // v = L⁻¹ k*: sweep the columns, lane = row
@@ -970,6 +972,19 @@ __global__ __launch_bounds__(SPG_THREADS) void small_predict_grad_kernel(const d
         }
         if (lane >= N) v0 = 0.0;
         double sm = v0 * zs[lane] + v1 * zs[lane + 64], sv = v0 * v0 + v1 * v1;
+        if (!GRAD) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sm += __shfl_xor(sm, off);
+                sv += __shfl_xor(sv, off);
+            }
+            if (lane == 0) {
+                mu[j] = (mean_s ? mean_s[j] : 0.0) + sm;
+                var[j] = amp2 - sv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every lane has read k* before v overwrites it
         kv[lane] = v0;
         kv[lane + 64] = v1;
