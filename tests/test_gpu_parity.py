@@ -932,7 +932,7 @@ def test_two_host_threads_share_a_device(api, O):
 
 
 @pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
-@pytest.mark.parametrize("d,N,M", [(1, 5, 3), (2, 1, 7), (2, 20, 224), (4, 64, 1), (5, 127, 300), (32, 128, 65), (3, 100, 3000), (3, 130, 45), (8, 700, 100),
+@pytest.mark.parametrize("d,N,M", [(1, 5, 3), (2, 1, 7), (2, 20, 224), (4, 64, 1), (5, 127, 300), (32, 128, 65), (2, 20, 5000), (3, 100, 3000), (3, 130, 45), (8, 700, 100),
                                    (17, 300, 33)])   # N <= 128 with d <= 32: the single-launch kernel
 def test_posterior_gradients(api, O, kernel, d, N, M):
     """boss_gp_predict_grad: mean / variance and their gradients w.r.t. the candidates
