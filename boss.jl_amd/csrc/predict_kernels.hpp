@@ -14,11 +14,12 @@ namespace boss {
 // which is the blocked form of  V = C.U' \ K*  (AbstractGPs var(post(X*))), with
 // μ − m(X*) = K*^T a = V^T z  accumulated in the same pass.  K* never touches HBM.
 // ------------------------------------------------------------------------------------------
+constexpr int PRED_CS_MAX_D = 16;                   // x_dim up to which the workgroup's scaled candidates are staged in LDS
 template <class G>
 struct PredictLds {
     static constexpr int LDR = G::BN + 16;
     static constexpr int PART = 2 * G::TN * 4;       // per-thread Σv², v·z partials, parked in LDS between row blocks
-    static constexpr int BYTES = (G::BM * LDR + 2 * G::WR * G::BN + G::NTHREADS * PART) * 8;
+    static constexpr int BYTES = (G::BM * LDR + 2 * G::WR * G::BN + G::NTHREADS * PART + PRED_CS_MAX_D * G::BN) * 8;
 };
 
 // G = GemmDirect<WR,1,TM,TN,D> with RB = WR·TM·16 ∈ {128, 256}: WR waves stacked along the RB rows of a
@@ -62,6 +63,15 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
     double* part = red + 2 * G::WR * G::BN;
 #pragma unroll
     for (int u = 0; u < 2 * TN * 4; ++u) part[u * G::NTHREADS + tid] = 0.0;
+    // The K* phase sits between the two GEMMs of every row block with nothing to hide behind: its operand loads must not come
+    // one coordinate at a time (eight dependent L2 round trips per block cost more than its arithmetic).  The candidates'
+    // coordinates — the same for every row block — are staged in LDS once, the rows' coordinates are fetched four at a time (eight would spill).
+    double* cs = part + (size_t)G::NTHREADS * PredictLds<G>::PART;
+    const bool cs_ok = !PRE && d <= PRED_CS_MAX_D;
+    if (cs_ok) {
+        for (int idx = tid; idx < d * BN; idx += G::NTHREADS) cs[idx] = Csc[(size_t)(idx / BN) * Mp + c0 + (idx % BN)];
+        __syncthreads();
+    }
 
     for (int ib = 0; ib < nblk; ++ib) {
         v4d acc[TM][TN];
@@ -79,6 +89,32 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
             for (int n = 0; n < TN; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) r2[m][n][i] = 0.0;
+        if (cs_ok && !(dbg & 1)) {
+            for (int kd0 = 0; kd0 < d; kd0 += 4) {
+                double xr[4][TM];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+                        xr[kk][m] = (kd0 + kk < d) ? Xsc[(size_t)(kd0 + kk) * Np + ib * RB + G::row_of(wr, m, lane)] : 0.0;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kd0 + kk < d) {
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const double xc = cs[(kd0 + kk) * BN + G::col_of(wc, n, i, lane)];
+#pragma unroll
+                                for (int m = 0; m < TM; ++m) {
+                                    const double diff = xr[kk][m] - xc;
+                                    r2[m][n][i] = __builtin_fma(diff, diff, r2[m][n][i]);
+                                }
+                            }
+                    }
+                }
+            }
+        } else
         for (int kd = 0; kd < ((dbg & 1) || PRE ? 0 : d); ++kd) {
             double xr[TM], xc[TN][4];
 #pragma unroll
