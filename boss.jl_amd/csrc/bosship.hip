@@ -262,6 +262,8 @@ struct boss_gp {
     double amp2 = 0.0;
     bool has_mean = false, fitted = false, pending = false, have_dinv = false;
     bool dinv_used = false;                    // the current block inverses were used by a prediction (see factor_enqueue)
+    bool dinv_used_prev = false;               // its value when the pending update was enqueued (restored if that update is repeated)
+    bool gated = false;                        // the pending update was enqueued with gate kernels
     double* host_res = nullptr;                // pinned: scal[2], info
     double* host_res_dev = nullptr;            // the same memory through its device address (written by small_fit_kernel / potrf_logdet_kernel)
     bool par_in_args = false;                  // this update's hyper-parameters travel in the first kernel's arguments
@@ -270,7 +272,9 @@ struct boss_gp {
     double* host_par = nullptr;                // pinned staging: invlam[d], hyp[2]
     hipEvent_t par_ev = nullptr;               // recorded after the staging copies were enqueued
     unsigned long long epoch = 0;              // bumped by every boss_gp_update: tracked candidate states go stale
-    unsigned long long dinv0_epoch = ~0ull;    // epoch at which block 0 of Dinv was built on its own (the small-N prediction kernels need nothing else)
+    // factor_gen: bumped whenever the resident factor changes (update, append of any kind, storage growth, re-factorisation);
+    // dinv0_gen: the generation at which block 0 of Dinv was built on its own (the small-N prediction kernels need nothing else)
+    unsigned long long factor_gen = 0, dinv0_gen = ~0ull;
     hipEvent_t dinv_ev = nullptr;              // the side stream finished building Dinv / Dinv2
     bool dinv_pending = false;
     // gradient-observation posterior (GradientGaussianProcess): npts points, N = npts (1 + d) observations,

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel(double* __rest
 #pragma unroll
         for (int m = 0; m < TRSM_NA; ++m) {
 #pragma unroll 1
-            for (int spin = 0; spin < (1 << 20) && *(volatile lds_int_t*)&ready <= m; ++spin) __builtin_amdgcn_s_sleep(1);
+            while (*(volatile lds_int_t*)&ready <= m) __builtin_amdgcn_s_sleep(1);   // (wave 0 of this workgroup: it never waits for this wave)
             asm volatile("" ::: "memory");
             const v4d x = xs[m][lane];
 #pragma unroll

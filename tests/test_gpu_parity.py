@@ -795,6 +795,44 @@ def test_block_cholesky_append(api, O, N0, steps):
     g.close()
 
 
+@pytest.mark.parametrize("N0", [5, 20, 100])
+def test_small_posterior_predict_then_append_then_predict(api, O, N0):
+    """The reference's own regime (a BO loop or SequentialBatchAM at N ≈ 20): update → predict (single-launch kernels on
+    block 0 of the block inverses) → append → predict / acquisition / gradients.  The block of L⁻¹ that the small kernels
+    read must be rebuilt after every append (it used to be keyed on the update count only)."""
+    rng = np.random.default_rng(900 + N0)
+    d, M = 2, 37
+    Ntot = N0 + 1 + 3
+    X = rng.uniform(0, 1, (d, Ntot))
+    y = np.sin(3 * X).sum(0) + 0.05 * rng.standard_normal(Ntot)
+    Xs = rng.uniform(0, 1, (d, M))
+    lam, amp, sig = np.array([0.4, 0.6]), 1.1, 0.05
+    g = api.GP(X[:, :N0], y[:N0], "matern52")
+    g.update(lam, amp, sig)
+    cand = api.Candidates(Xs)
+    n_at = N0
+    for n in (1, 3):
+        # a prediction and an acquisition call BEFORE the append mark block 0 as built for this update
+        g.predict(Xs)
+        api.acq_ei([[g]], cand, [1.0], None, float(y[:n_at].max()))
+        g.append(X[:, n_at:n_at + n], y[n_at:n_at + n])
+        n_at += n
+        post = O.gp_fit(X[:, :n_at], y[:n_at], "matern52", lam, amp, sig)
+        mu_o, var_o = O.gp_mean_and_var(post, Xs)
+        mu, var = g.predict(Xs)
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9), (N0, n_at)
+        best = float(y[:n_at].max())
+        acq, am, _ = api.acq_ei([[g]], cand, [1.0], None, best)
+        acq_o = O.ei_acquisition([post], Xs, [1.0], None, best)
+        assert np.allclose(acq, acq_o, rtol=0, atol=1e-10) and am == int(np.argmax(acq_o)), (N0, n_at)
+        mu2, var2, dmu, dvar = g.predict_grad(Xs)
+        _, _, dmu_o, dvar_o = O.gp_mean_and_var_grad(post, Xs)
+        assert np.allclose(mu2, mu_o, rtol=0, atol=1e-9) and np.allclose(var2, O.clip_var(var_o), rtol=0, atol=1e-9)
+        assert np.allclose(dmu, dmu_o, rtol=0, atol=1e-8 * (1 + np.abs(dmu_o).max()))
+        assert np.allclose(dvar, dvar_o, rtol=0, atol=1e-8 * (1 + np.abs(dvar_o).max()))
+    g.close()
+
+
 def test_append_zero_mean_discrete_and_errors(api, O):
     rng = np.random.default_rng(3)
     d, N0, n = 2, 140, 5

@@ -3,8 +3,11 @@ sys.path.insert(0,'/root/repo')
 import numpy as np
 from boss_jl_amd import api
 if os.environ.get('BOSS_LIB'): api.load_library(os.environ['BOSS_LIB'])
-sys.path.insert(0,'/root/repo/tests')
-from gpu_quick import problem
+def problem(d, N, M, seed=1, noise=0.05):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(2 * np.pi * X).sum(0) / np.sqrt(d) + noise * rng.standard_normal(N)
+    return X, y, np.random.default_rng(seed + 1).uniform(0, 1, (d, M))
 X,y,Xs=problem(8,4096,8192)
 g=api.GP(X,y,"matern52"); g.update(np.full(8,.5),1.0,0.05)
 cand=api.Candidates(Xs); b=float(y.max())
