@@ -19,6 +19,7 @@
 
 #include "gp_kernels.hpp"
 #include "potrf.hpp"
+#include "chain.hpp"
 
 using namespace boss;
 
@@ -84,6 +85,12 @@ struct Ctx {
     // (tools/streamwait_probe.hip, profiles/r02_chain_timeline_waitvalue.log).  nullptr (BOSS_NO_GATE=1): events.
     unsigned long long* sig_panel = nullptr;
     unsigned long long sig_seq = 0;
+    // the resident panel chain (chain.hpp): its own stream, the base of its sequence numbers, and whether it may be used at all
+    // (it needs kernels of different streams to run at the same time: off wherever launches are known to be serialised)
+    hipStream_t chain_stream = nullptr, strip_stream = nullptr;
+    unsigned long long chain_seq = 0, crit_seq = 0;
+    bool chain_ok = false;
+    bool test_drop_chain = false;              // BOSS_TEST_DROP_CHAIN=1: the chain kernel is never launched (exercises the fallback)
     unsigned long long acq_seq = 0;            // sequence number of the arg-max result block (boss_acq_ei polls it)
     bool lookahead = true;
     bool prof_on = false;
@@ -101,6 +108,13 @@ struct Ctx {
     std::mutex mtx;
 };
 
+// the resident chain kernels (chain.hpp) run on streams of their own and nothing is ordered behind them: whoever frees or
+// re-lays-out memory they touch waits for them first (they end within microseconds of the update's last kernel)
+static void chain_quiesce(Ctx* c) {
+    if (c->chain_stream) (void)hipStreamSynchronize(c->chain_stream);
+    if (c->strip_stream) (void)hipStreamSynchronize(c->strip_stream);
+}
+
 static std::mutex g_ctx_mtx;
 static std::map<int, Ctx*> g_ctx;
 
@@ -108,6 +122,8 @@ static void ctx_destroy(Ctx* c) {
     if (!c) return;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
+    if (c->strip_stream) (void)hipStreamDestroy(c->strip_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->sig_panel) (void)hipFree(c->sig_panel);
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
@@ -127,6 +143,8 @@ static int ctx_init(Ctx* c) {
         HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest));
         c->stream = c->own_stream;
         HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
+        HIPCHK(hipStreamCreateWithPriority(&c->chain_stream, hipStreamNonBlocking, greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->strip_stream, hipStreamNonBlocking, greatest));
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
@@ -148,14 +166,18 @@ static int ctx_init(Ctx* c) {
                                      getenv("ROCPROF_COUNTER_GROUPS") || set_nonzero("ROCPROF_ADVANCED_THREAD_TRACE") ||
                                      getenv("ROCPROF_ATT_PARAM_SERIALIZE_ALL") || getenv("ROCP_METRICS") || set_nonzero("AMD_SERIALIZE_KERNEL");
         if (!gate_off) {
-            HIPCHK(hipMalloc((void**)&c->sig_panel, 64));
-            HIPCHK(hipMemset(c->sig_panel, 0, 64));
+            HIPCHK(hipMalloc((void**)&c->sig_panel, SIG_WORDS * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(c->sig_panel, 0, SIG_WORDS * sizeof(unsigned long long)));
         }
+        // (gates are enqueued behind their producers and survive launches that execute one at a time; the resident chain cannot)
+        c->chain_ok = !gate_off && !set_nonzero("BOSS_NO_CHAIN") && !set_nonzero("HIP_LAUNCH_BLOCKING");
+        c->test_drop_chain = set_nonzero("BOSS_TEST_DROP_CHAIN");
     }
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
     std::memset(c->pinned, 0, PINNED_UP_OFF);                              // (the polled sequence words start from a known value)
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_llgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LLG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
@@ -433,3 +455,24 @@ extern "C" int boss_prof_get(int device, const char* kernel_class, double* ms_to
     if (launches) *launches = n;
     return BOSS_OK;
 }
+
+#ifdef BOSS_CHAIN_TRACE
+// (tools/chain_trace3.py) read and reset the resident chain's device timeline
+extern "C" int boss_debug_ctrace(unsigned long long* chain /*64*16*/, unsigned long long* colupd /*64*4*/, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (chain && hipMemcpyFromSymbol(chain, HIP_SYMBOL(boss::g_ctrace), sizeof(unsigned long long) * 64 * 16) != hipSuccess) return 1;
+    if (colupd && hipMemcpyFromSymbol(colupd, HIP_SYMBOL(boss::g_cutrace), sizeof(unsigned long long) * 64 * 4) != hipSuccess) return 1;
+    if (colupd && hipMemcpyFromSymbol(colupd + 64 * 4, HIP_SYMBOL(boss::g_ptrace), sizeof(unsigned long long) * 64 * 32) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long a[64 * 16], b[64 * 4];
+        for (int i = 0; i < 64; ++i) {
+            for (int j = 0; j < 16; ++j) a[i * 16 + j] = (j == 5) ? ~0ull : 0ull;
+            b[i * 4 + 0] = ~0ull;
+            b[i * 4 + 1] = b[i * 4 + 2] = b[i * 4 + 3] = 0;
+        }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(boss::g_ctrace), a, sizeof a);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(boss::g_cutrace), b, sizeof b);
+    }
+    return 0;
+}
+#endif

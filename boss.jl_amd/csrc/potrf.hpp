@@ -16,6 +16,13 @@
 
 namespace boss {
 
+#ifdef BOSS_CHAIN_TRACE
+__device__ unsigned long long g_cutrace[64 * 4];            // column-update kernel: earliest entry / latest exit per step
+__device__ unsigned long long g_ptrace[64 * 32];            // inside the published diagonal block: per panel, wave 0 / wave 15 stamps
+#define PTRACE(col0, jb, slot) do { if ((threadIdx.x & 63) == 0) g_ptrace[(((col0) / BLK) & 63) * 32 + (slot) * 8 + (jb)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PTRACE(col0, jb, slot) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Diagonal block: unblocked 16-column panels (lane = row, pivots broadcast with v_readlane),
@@ -105,6 +112,61 @@ __device__ __forceinline__ void chol16_unscaled(v4d& S, v4d& E, double (&ipsel)[
 __device__ __forceinline__ int lp_index(int R, int C) { return ((R * 4 + (C & 3)) * 4) + (C >> 2); }
 
 // ------------------------------------------------------------------------------------------
+// Hand-offs between workgroups that run at the same time (the persistent panel chain and its followers, below).
+// Form used (MI355X_MICROARCH.md, "Valid forms"): EVERY handed-off byte is stored with an agent-scope (sc1, write-through)
+// store, the storing wave drains its stores (s_waitcnt vmcnt(0)) and then one lane stores / raises the sequence word (sc1);
+// the consumer polls the word with sc1 loads and reads the bytes with sc1 loads only after its poll has matched (other waves
+// of its workgroup: after a barrier the polling wave joins).  Sequence words only ever grow (one base per factorisation).
+// ------------------------------------------------------------------------------------------
+// (explicit global address space: on a generic pointer these builtins become flat_ instructions, which count on lgkmcnt as
+// well — a publishing wave would then stall at the next LDS-only barrier until its stores have landed — and flat sc1 loads are
+// not among the measured-valid hand-off forms)
+typedef __attribute__((address_space(3))) int lds_int_t;
+typedef __attribute__((address_space(1))) unsigned long long gmem_u64;
+typedef __attribute__((address_space(1))) int gmem_i32;
+__device__ __forceinline__ gmem_u64* as_global(const void* p) { return (gmem_u64*)(unsigned long long)p; }
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store(as_global(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(as_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned long long ld_word(const unsigned long long* w) {
+    return __hip_atomic_load(as_global(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_info(const int* p) {
+    return __hip_atomic_load((gmem_i32*)(unsigned long long)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_info(int* p, int v) {
+    __hip_atomic_store((gmem_i32*)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16 bytes per lane, write-through (there is no 16-byte atomic builtin).  The s_nop covers the wait state a VALU write to the
+// data registers needs behind a wide store: the compiler's hazard recogniser does not look inside inline asm.
+__device__ __forceinline__ void st_sc1_x4(double* p, v2d v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(as_global(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void raise_word(unsigned long long* w, unsigned long long v) {
+    __hip_atomic_store(as_global(w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// word indices inside the context's signal block (each group on a 128-byte line of its own)
+constexpr int SIGW_GATE = 0, SIGW_BULK = 3, SIGW_PANEL = 16, SIGW_WDONE = 32, SIGW_PROG = 48, SIGW_CRIT = 64, SIG_WORDS = 80;
+constexpr int POLL_SPINS = 1 << 20;                        // ≈ 1 s: something lets only one kernel run at a time -> info = INT_MIN, the host falls back
+// One wave waits until *w >= v (wave-uniform).  false: gave up (timeout, or another waiter already marked the factorisation).
+__device__ __forceinline__ bool poll_ge(const unsigned long long* w, unsigned long long v, int* info) {
+    for (int i = 0; i < POLL_SPINS; ++i) {
+        if (ld_word(w) >= v) {
+            asm volatile("" ::: "memory");
+            return true;
+        }
+        if ((i & 1023) == 1023 && ld_info(info) == INT_MIN) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if ((threadIdx.x & 63) == 0) st_info(info, INT_MIN);
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
 // Diagonal block (128×128, LDS-resident), 16-column panels, look-ahead inside the block:
 //   phase A  wave 0 alone runs the sequential pivot chain on the diagonal 16×16 tile (chol16_unscaled) — meanwhile the
 //            update waves are still applying the PREVIOUS panel's rank-16 update to the rest of the block;
@@ -131,15 +193,25 @@ __device__ __forceinline__ int dtile(int i, int j) { return (i * (i + 1) / 2 + j
 // inv16 format) for a caller that goes on to solve with the factor inside the same kernel (small_fit_kernel).
 // TILE0_GLOBAL: the pivot-chain wave takes diagonal tile 0 straight from global memory (the caller did not wait for the
 // workgroup's LDS fill: the chain starts while the other waves are still loading; barrier 1 of the first panel orders the fill).
-template <bool KEEP = false, bool TILE0_GLOBAL = false>
+// PUB: the block is factored by the persistent chain (potrf_chain_kernel) while followers on other CUs consume it panel by
+// panel: everything that leaves for global memory goes out with sc1 stores from wave 15 (idle in phase B, not on the pivot
+// chain's SIMD), which then drains its stores and raises pubword to pubseq0 + jb + 1 = "panel jb of this block is out: the
+// inverse of its diagonal tile and its row tiles" (the last panel has no row tiles: its word follows barrier 1 directly).  A failed
+// pivot is written to info by the pivot-chain wave itself before that panel's barrier (nobody is stream-ordered behind this kernel).
+template <bool KEEP = false, bool TILE0_GLOBAL = false, bool PUB = false>
 __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, double* __restrict__ A, int ld,
                                                   double* __restrict__ inv16, int col0, int nsub, int& fail,
-                                                  double* __restrict__ Is = nullptr) {
+                                                  double* __restrict__ Is = nullptr, unsigned long long* pubword = nullptr,
+                                                  unsigned long long pubseq0 = 0, int* info = nullptr, int tidtok = 0) {
     double* D = smem;
     double* Es = smem + DIAG_TILES * 256;            // E' = L16^{-T}·diag(√p) of the current panel, lane-private layout
     double* Ss = Es + 256;                           // S' = L16·diag(√p), lane-private layout
-    volatile int* xread = reinterpret_cast<volatile int*>(Ss + 256);   // panel whose first row tile wave 0 has finished reading
-    const int tid = threadIdx.x, lane = tid & 63;
+    // panel whose first row tile wave 0 has finished reading (explicit LDS address space: a volatile access through a generic
+    // pointer is a flat_ instruction, and the wave that spins on it then waits on vmcnt as well)
+    volatile lds_int_t* xread = (volatile lds_int_t*)(unsigned)(unsigned long long)(Ss + 256);
+    // (tidtok: an opaque zero the persistent chain kernel passes so that the per-lane offsets below are recomputed per block instead
+    // of being hoisted out of its block loop, where they would stay live — and spill — through the follower phase)
+    const int tid = threadIdx.x + tidtok, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: tile decode runs on the SALU
     const int r16 = lane & 15, q = lane >> 4;
     constexpr int NW = DIAG_THREADS / 64;
@@ -179,17 +251,25 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
         // ---------------- phase A ----------------
         if (wave == 0) {
             v4d E;
+            if constexpr (PUB) PTRACE(col0, jb, 0);
             chol16_unscaled(S, E, ipsel, lane, col0 + jb * 16, fail);
+            if constexpr (PUB) PTRACE(col0, jb, 1);
             *reinterpret_cast<v4d*>(Es + olp) = E;
             *reinterpret_cast<v4d*>(Ss + olp) = S;
-        } else if (jb > 0 && (wave & 3) != 0) {
+            if constexpr (PUB) {
+                if (fail >= 0) {                              // (rare) reported before this panel is published
+                    if (lane == 0 && ld_info(info) == 0) st_info(info, fail + 1);
+                    drain_stores();
+                }
+            }
+        } else if (jb > 0 && (wave & 3) != 0 && !(PUB && wave == 15)) {
             // rest of the rank-16 update with panel jb-1 (tile (jb,jb) was done by wave 0 in phase B).
             // Waves 4, 8, 12 share wave 0's SIMD: they stay idle here, so the pivot chain's MFMAs and
             // VALU ops never queue behind update MFMAs (measured: 5450 → 3980 cycles per 16-column chain).
             const int jp = jb - 1, tp = nsub - 1 - jp;
             const int T = tp * (tp + 1) / 2;
             constexpr int U = 2;                                // (U = 3 would cover panel 0's 27 tiles in one round, but the extra registers slow every round: measured)
-            constexpr int NUPD = NW - NW / 4;                   // 12 update waves
+            constexpr int NUPD = NW - NW / 4 - (PUB ? 1 : 0);   // 12 update waves (PUB: 11 — wave 15 only publishes)
             const int uw = wave - 1 - (wave >> 2);              // 0..11
             for (int q0 = 1 + uw; q0 < T; q0 += U * NUPD) {     // update waves cover tile indices 1..T-1
                 int ti[U], tj[U];
@@ -239,11 +319,22 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
             for (int i = 0; i < 4; ++i) {
                 const double rs = rsqrt_refined(Ss[od[i]]);          // 1/√p of column c = q + 4i
                 const int c = q + 4 * i;
-                if (r16 >= c) At[(size_t)c * ld + r16] = Sv[i] * rs;
-                inv16[jb * 256 + r16 * 16 + c] = Ev[i] * rs;        // inv(L16)(c, r16) = E(r16, c), stored at r16*16 + c
+                if constexpr (PUB) {
+                    if (r16 >= c) st_sc1(At + (size_t)c * ld + r16, Sv[i] * rs);
+                    st_sc1(inv16 + jb * 256 + r16 * 16 + c, Ev[i] * rs);
+                } else {
+                    if (r16 >= c) At[(size_t)c * ld + r16] = Sv[i] * rs;
+                    inv16[jb * 256 + r16 * 16 + c] = Ev[i] * rs;        // inv(L16)(c, r16) = E(r16, c), stored at r16*16 + c
+                }
                 if constexpr (KEEP) {
                     D[dtile(jb, jb) + oel[i]] = (r16 >= c) ? Sv[i] * rs : 0.0;
                     Is[jb * 256 + r16 * 16 + c] = Ev[i] * rs;
+                }
+            }
+            if constexpr (PUB) {
+                if (t == 0) {                                 // last panel: nothing else to publish
+                    drain_stores();
+                    if (lane == 0) raise_word(pubword, pubseq0 + jb + 1);
                 }
             }
         }
@@ -299,6 +390,24 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
             for (int i = 0; i < 4; ++i) Xt[oel[i]] = pv[i];
         }
         lds_barrier();                                // barrier 2: panel jb final
+        if constexpr (PUB) {
+            if (wave == 15) {
+                for (int tr = jb + 1; tr < nsub; ++tr) {
+                    const double* src = D + dtile(tr, jb);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = lane + 64 * h, c = e >> 3, rp = e & 7;
+                        st_sc1_x4(A + (size_t)(jb * 16 + c) * ld + tr * 16 + 2 * rp, *reinterpret_cast<const v2d*>(src + c * 16 + 2 * rp));
+                    }
+                }
+                // panel jb is out: its inverse / diagonal tile (stored after barrier 1) and its row tiles.  (This wave takes no part
+                // in the next phase A's update, so the wait costs the block nothing.)
+                PTRACE(col0, jb, 2);
+                drain_stores();
+                PTRACE(col0, jb, 3);
+                if (lane == 0) raise_word(pubword, pubseq0 + jb + 1);
+            }
+        }
         if constexpr (TILE0_GLOBAL) {
             // the finished row tiles of this panel leave for global memory now, from a wave that has nothing else to do (12: idle
             // in both phases), instead of in a copy loop behind the last panel
@@ -630,7 +739,6 @@ __device__ __forceinline__ void wave_trsm16(const double* __restrict__ Lkk, int 
 // ascending column order, so the result is bit-identical to the one-wave form (wave_trsm16, kept for the block inverses).
 constexpr int TRSM_NA = 5;
 constexpr int TRSM_THREADS = 128;
-typedef __attribute__((address_space(3))) int lds_int_t;
 __global__ __launch_bounds__(TRSM_THREADS) void potrf_trsm_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
                                                                   const double* __restrict__ inv16base,
                                                                   size_t inv16_bstride, int row0) {
@@ -1075,7 +1183,8 @@ constexpr int SYRK_LDS_BYTES = 0;
 
 // acc is INITIALISED from C (its load latency overlaps the operand prologue), updated with
 // acc -= P_i P_j^T, and stored back: the epilogue is pure stores.
-template <class G>
+// SC1: the tile is stored write-through (a resident kernel on another CU reads it while this kernel is still running)
+template <class G, bool SC1 = false>
 __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k, int R0, int C0, int K = BLK) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / G::WC, wc = wave % G::WC;
@@ -1102,7 +1211,9 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k,
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v2d c2 = {acc[m][n][i], acc[m + 1][n][i]};
-                *reinterpret_cast<v2d*>(C + G::row_of(wr, m, lane) + (size_t)G::col_of(wc, n, i, lane) * ld) = c2;
+                double* dst = C + G::row_of(wr, m, lane) + (size_t)G::col_of(wc, n, i, lane) * ld;
+                if constexpr (SC1) st_sc1_x4(dst, c2);
+                else *reinterpret_cast<v2d*>(dst) = c2;
             }
 }
 
@@ -1116,7 +1227,8 @@ typedef GemmDirect<2, 2, 2, 4, 4> SyrkHalfG;   // 64×128 half tile: workgroups 
 
 template <int NPAN, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                            int first, int m, int batch1d) {
+                                                            int first, int m, int batch1d, int skip00 = 0) {
+    if (skip00 && blockIdx.x == 0) return;                  // tile (first, first) is updated by the column-update kernel (chain schedule)
     constexpr int npan = NPAN;                              // compile-time K keeps the tile loop inside the register budget
     // npan adjacent panels k..k+npan-1 applied in one pass (K = 128·npan): the batched schedule pairs
     // panels so every trailing tile is read and written half as often.
@@ -1148,9 +1260,18 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
     }
 }
 
+// skipdiag: the four strips of tile (k+1, k+1) are left out — the persistent chain applies panel k to that tile itself (chain.hpp);
+// xblk >= 0: four extra strips update the diagonal tile (xblk, xblk) with the same panel(s), so that every diagonal tile has
+// received every panel but the last one a whole step before its own factorisation (even steps: xblk = k+2; odd steps: k+3,
+// which the bulk update then leaves out).
 __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
                                                               int m, int ncols, int jfirst, int npan,
-                                                              unsigned long long* wword, unsigned long long wval, int* info) {
+                                                              unsigned long long* wword, unsigned long long wval, int* info,
+                                                              int skipdiag, int xblk, unsigned long long* critw) {
+#ifdef BOSS_CHAIN_TRACE
+    if (threadIdx.x == 0) atomicMin(&g_cutrace[(k & 63) * 4 + 0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    struct TraceEnd { int k; __device__ ~TraceEnd() { if (threadIdx.x == 0) atomicMax(&g_cutrace[(k & 63) * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } trace_end_{k};
+#endif
     wait_word(wword, wval, info);                            // (look-ahead schedule: the bulk update that wrote these columns before)
     // npan = 2: apply the TWO panels k-1, k (K = 256) — the odd steps of the paired look-ahead schedule
     // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
@@ -1159,6 +1280,36 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     __builtin_amdgcn_s_setprio(3);           // a chain kernel: its waves win issue arbitration over co-resident bulk-update waves
     double* A = Abase + (size_t)blockIdx.z * bstride;
     int t = blockIdx.x;
+    if (critw) {
+        // dispatch order: the eight critical strips first — tile (k+2, k+1) = strips 4..7 of this list, tile (k+2, k+2) = the extra
+        // strips at its end (even steps) or the first four strips of the second column — swapped with strips 0..3 (the left-out
+        // diagonal tile: nothing to do) and 4..7
+        const int G = (int)gridDim.x;
+        const int d0 = (xblk == k + 2) ? G - 4 : 4 * m + 1;
+        if (t < 4) t = 4 + t;
+        else if (t < 8) t = d0 + (t - 4);
+        else if (t >= d0 && t < d0 + 4) t = t - d0;
+    }
+    // critw: the strips of tiles (k+2, k+1) and (k+2, k+2) — what the resident chain needs first for step k+1 — store write-through
+    // and count themselves in (eight per step); the resident kernels start on those tiles while the rest of this launch is still running
+    auto crit_done = [&]() {
+        drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(critw), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (xblk >= 0 && t >= (int)gridDim.x - 4) {
+        const int R0 = xblk * BLK + (t - ((int)gridDim.x - 4)) * 32;
+        if (critw && xblk == k + 2) {
+            if (npan == 2) syrk_tile<RhsG, true>(A, ld, k - 1, R0, xblk * BLK, 2 * BLK);
+            else syrk_tile<RhsG, true>(A, ld, k, R0, xblk * BLK);
+            crit_done();
+            return;
+        }
+        if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, R0, xblk * BLK, 2 * BLK);
+        else syrk_tile<RhsG>(A, ld, k, R0, xblk * BLK);
+        return;
+    }
+    if (skipdiag && t < 4) return;                            // column k+1's strips 0..3 = its diagonal tile
     int j = jfirst;                                           // first trailing block column handled (0 = column k+1)
     if (ncols > 1) {
         // column j has 4*(m-j)+1 strips
@@ -1169,6 +1320,12 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     }
     const int nstr = 4 * (m - j);
     const int R0 = (t < nstr) ? (k + 1 + j) * BLK + t * 32 : (k + 1 + m) * BLK;
+    if (critw && t < nstr && R0 / BLK == k + 2 && j <= 1) {       // tile (k+2, k+1) or (k+2, k+2)
+        if (npan == 2) syrk_tile<RhsG, true>(A, ld, k - 1, R0, (k + 1 + j) * BLK, 2 * BLK);
+        else syrk_tile<RhsG, true>(A, ld, k, R0, (k + 1 + j) * BLK);
+        crit_done();
+        return;
+    }
     if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, R0, (k + 1 + j) * BLK, 2 * BLK);
     else syrk_tile<RhsG>(A, ld, k, R0, (k + 1 + j) * BLK);
 }
