@@ -172,6 +172,20 @@ static int ctx_init(Ctx* c) {
         // (gates are enqueued behind their producers and survive launches that execute one at a time; the resident chain cannot)
         c->chain_ok = !gate_off && !set_nonzero("BOSS_NO_CHAIN") && !set_nonzero("HIP_LAUNCH_BLOCKING");
         c->test_drop_chain = set_nonzero("BOSS_TEST_DROP_CHAIN");
+        if (c->chain_ok) {
+            // can kernels of the side, chain and strip streams run beside one of the main stream?  (see chain_probe_wait_kernel)
+            int* okw = nullptr;
+            HIPCHK(hipMalloc((void**)&okw, 3 * sizeof(int)));
+            HIPCHK(hipMemset(okw, 0, 3 * sizeof(int)));
+            hipStream_t waiters[3] = {c->side_stream, c->chain_stream, c->strip_stream};
+            for (int i = 0; i < 3; ++i)
+                hipLaunchKernelGGL(chain_probe_wait_kernel, dim3(1), dim3(64), 0, waiters[i], c->sig_panel + SIGW_NEAR + 1, 1ull, okw + i);
+            hipLaunchKernelGGL(potrf_publish_kernel, dim3(1), dim3(64), 0, c->own_stream, c->sig_panel + SIGW_NEAR + 1, 1ull);
+            int okh[3] = {0, 0, 0};
+            bool fine = hipDeviceSynchronize() == hipSuccess && hipMemcpy(okh, okw, sizeof okh, hipMemcpyDeviceToHost) == hipSuccess;
+            (void)hipFree(okw);
+            if (!(fine && okh[0] && okh[1] && okh[2])) c->chain_ok = false;
+        }
     }
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)
     std::memset(c->pinned, 0, PINNED_UP_OFF);                              // (the polled sequence words start from a known value)

@@ -37,12 +37,12 @@ __device__ unsigned long long g_ctrace[64 * 16];
 // costs one reload of the thread index per phase.
 #define CHAIN_CUT_VGPRS() asm volatile("" ::: "memory", "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119")   // (v120-v127 stay: SGPR spill lanes, the thread index)
 constexpr int CHAIN_CTRL = DIAG_TILES * 256 + DIAG_STAGE;   // doubles: one control word behind the diagonal-block kernel's LDS
-constexpr int CHAIN_LDS_BYTES = (CHAIN_CTRL + 2) * 8;
+constexpr int CHAIN_LDS_BYTES = (CHAIN_CTRL + 2) * 8;       // two control words (ints): go-ahead of the block, posted panel count
 
 // sig[SIGW_WDONE] >= base + k + 1 : follow kernel k has STARTED, i.e. everything enqueued before it on the main stream has
 //                                   completed (column k of the matrix carries every panel < k; tile (k+1, k+1) every panel < k)
 // sig[SIGW_PANEL] >= base + 8 b + jb + 1 : panel jb of diagonal block b is out (inverse of its diagonal tile, its row tiles)
-// sig[SIGW_PROG + s] >= base + 8 k + jb + 1 : strip s (of the eight strips of block row k+1) has stored its tile of panel jb of step k
+// sig[SIGW_PROG + SIGW_PROG_STRIDE s] >= base + 8 k + jb + 1 : strip s (of the eight strips of block row k+1) has stored its tile of panel jb of step k
 //
 // The two phases are separate (non-inlined) functions: inlined into one loop body the register allocator keeps the factorisation's
 // per-lane state alive through the follower phase and spills it (the follower rounds then wait on scratch loads: 10 µs each).
@@ -55,9 +55,9 @@ constexpr int CHAIN_LDS_BYTES = (CHAIN_CTRL + 2) * 8;
 // has fallen behind it takes two panels per round trip, and the next poll travels with the operand loads.
 // A wait that gives up marks the factorisation (info = INT_MIN) and the wave carries on without waiting: every loop of the
 // kernel stays bounded and every barrier is reached by all waves.
-__device__ const unsigned char chain_tile_tab[16][3] = {   // wave -> tile row, first tile column, number of tiles (36 lower tiles)
-    {7, 0, 3}, {7, 3, 3}, {7, 6, 2}, {6, 0, 3}, {6, 3, 2}, {6, 5, 2}, {5, 0, 2}, {5, 2, 2},
-    {5, 4, 2}, {4, 0, 3}, {4, 3, 2}, {3, 0, 2}, {3, 2, 2}, {2, 0, 3}, {1, 0, 2}, {0, 0, 1}};
+__device__ const unsigned char chain_tile_tab[16][3] = {   // wave -> tile row, first tile column, number of tiles (36 lower tiles; wave 15: none, it polls)
+    {7, 0, 3}, {7, 3, 3}, {7, 6, 2}, {6, 0, 3}, {6, 3, 2}, {6, 5, 2}, {5, 0, 3}, {5, 3, 3},
+    {4, 0, 3}, {4, 3, 2}, {3, 0, 2}, {3, 2, 2}, {2, 0, 3}, {1, 0, 2}, {0, 0, 1}, {0, 0, 0}};
 __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int ld, int b, int* __restrict__ info,
                                                              unsigned long long* __restrict__ sig, unsigned long long base) {
     extern __shared__ double smem[];
@@ -80,8 +80,11 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
     const unsigned long long pbase = base + 8ull * (b - 1);
     // this lane's element (row r16, k = q) of the tiles of P[b, b-1] (128 rows × 128 columns): + 16 t for row tile t, + (16 jb + 4 s) ld for k
     const double* Pl = A + (size_t)b * BLK + (size_t)(b - 1) * BLK * ld + (size_t)q * ld + r16;
-    auto poll_issue = [&]() { return lane < 8 ? ld_word(sig + SIGW_PROG + lane) : ~0ull; };
-    auto poll_eval = [&](unsigned long long v) {                       // panels all eight strips of block row b have delivered
+    // Wave 15 (one tile) polls the strips' progress words for the whole workgroup and posts the count in LDS; the others spin on
+    // that LDS word (sixteen waves polling the same lines in memory delayed each other's polls — and the strips' stores — by 2 µs).
+    volatile lds_int_t* seenw = (volatile lds_int_t*)(unsigned)(unsigned long long)(smem + CHAIN_CTRL) + 1;
+    auto poll_strips = [&]() {                                         // panels all eight strips of block row b have delivered
+        const unsigned long long v = lane < 8 ? ld_word(sig + SIGW_PROG + SIGW_PROG_STRIDE * lane) : ~0ull;
         const unsigned long long cnt = (v > pbase) ? v - pbase : 0ull;
         int mn = cnt > 8ull ? 8 : (int)cnt;
         mn = min(mn, __shfl_xor(mn, 1));
@@ -91,29 +94,45 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
     };
     int seen = 0, jb = 0;
     bool dead = false;
+    if (wave == 15) {
+        // the polling wave: posts every advance until the last panel is out (or the wait gives up: 99 releases everybody)
+        if (lane == 0) CTRACE(b, 1);
+        for (int it = 0; it < POLL_SPINS && seen < 8; ++it) {
+            const int mn = poll_strips();
+            asm volatile("" ::: "memory");
+            if (mn > seen) {
+                seen = mn;
+                if (lane == 0) *seenw = seen;
+                it = 0;
+            }
+            if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (seen < 8) {
+            if (lane == 0) {
+                st_info(info, INT_MIN);
+                *seenw = 99;
+            }
+        }
+        if (lane == 0) CTRACE(b, 2);
+        jb = 8;
+    }
 #pragma unroll 1
     while (jb < 8) {
         if (!dead && seen <= jb) {
             bool got = false;
-            for (int it = 0; it < POLL_SPINS; ++it) {
-                const int mn = poll_eval(poll_issue());
-                if (mn > jb) {
-                    seen = mn;
-                    got = true;
+            for (int it = 0; it < (POLL_SPINS << 3); ++it) {
+                const int v = *seenw;
+                if (v > jb) {
+                    seen = v;
+                    got = v <= 8;
                     break;
                 }
-                if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            asm volatile("" ::: "memory");
-            if (!got) {
-                dead = true;
-                if (lane == 0) st_info(info, INT_MIN);
-            }
+            if (!got) dead = true;
         }
-        if (wave == 0 && jb == 0) CTRACE(b, 1);
         const bool two = (dead || seen >= jb + 2) && jb + 2 <= 8;
-        if (wave == 0 && jb + (two ? 2 : 1) == 8) CTRACE(b, 2);
         const double* Pj = Pl + (size_t)(jb * 16) * ld;
         double bf[2][4], af[2][U][4];
 #pragma unroll
@@ -130,7 +149,12 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
                 for (int u = 0; u < U; ++u) af[1][u][s4] = ld_sc1(Pj + (size_t)(16 + 4 * s4) * ld + min(tj0 + u, ti) * 16);
             }
         }
-        const unsigned long long pnext = poll_issue();                 // (travels with the operand loads)
+#ifdef BOSS_CHAIN_TRACE
+        if (wave == 0 && jb + (two ? 2 : 1) == 8) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CTRACE(b, 11);
+        }
+#endif
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -142,9 +166,10 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
                 for (int u = 0; u < U; ++u) cr[u] = mfma_f64(-af[1][u][s4], bf[1][s4], cr[u]);
         }
         jb += two ? 2 : 1;
-        const int mn = poll_eval(pnext);
-        asm volatile("" ::: "memory");
-        seen = max(seen, mn);
+        if (!dead) {
+            const int v = *seenw;
+            if (v > seen && v <= 8) seen = v;
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -154,6 +179,7 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
             for (int i = 0; i < 4; ++i) ct[64 * i] = cr[u][i];
         }
     }
+    if (wave == 0) CTRACE(b, 12);
 }
 
 // C(b): the block in the LDS tile area is factored and published panel by panel.
@@ -184,7 +210,10 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __res
         // tile (b, b) as the critical strips of step b-2's column update stored it (sig[SIGW_CRIT] >= cbase + 8 (b-1))
         if (wave == 0) {
             const bool ok = b < 2 ? poll_ge(sig + SIGW_WDONE, base + 1, info) : poll_ge(sig + SIGW_CRIT, cbase + 8ull * (b - 1), info);
-            if (lane == 0) *ctrl = ok ? 1 : -1;
+            if (lane == 0) {
+                *ctrl = ok ? 1 : -1;
+                ctrl[1] = 0;                                  // (the follower phase's posted panel count)
+            }
         }
         __syncthreads();
         if (*ctrl < 0) return;
@@ -236,7 +265,7 @@ template <bool CRIT>
 __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int k, const double* __restrict__ inv16base,
                                              double* __restrict__ Brow, unsigned long long* __restrict__ prog,
                                              unsigned long long* __restrict__ sig, unsigned long long base, int* __restrict__ info,
-                                             v4d (&xs)[TRSM_NA][64], int& ready, int& drained) {
+                                             v4d (&xs)[TRSM_NA][64], int& ready, int& drained, int& avail) {
     constexpr bool crit = CRIT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -244,9 +273,13 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
     const double* inv16k = inv16base + (size_t)k * (8 * 256);
     const unsigned long long pb = base + 8ull * k;               // panel jb is out when sig[SIGW_PANEL] >= pb + jb + 1
     auto bload = [&](const double* p) { return crit ? ld_sc1(p) : *p; };   // (the resident strips read what a concurrent kernel stored)
+    // Only wave 0 polls the chain's panel word in memory; it posts the number of panels that are out in LDS (avail) and wave 1 waits
+    // on that (hundreds of follower waves polling one line in memory for a whole step slowed the bulk update they run beside).
+    auto panels_out = [&](unsigned long long v) { return v > pb ? (v - pb > 8ull ? 8 : (int)(v - pb)) : 0; };
     if (threadIdx.x == 0) {
         *(volatile lds_int_t*)&ready = 0;
         *(volatile lds_int_t*)&drained = 0;
+        *(volatile lds_int_t*)&avail = panels_out(ld_word(sig + SIGW_PANEL));
     }
     __syncthreads();
     auto lval = [&](int jb, int m, int s) { return ld_sc1(Lkk + (size_t)(m * 16 + 4 * s + (lane >> 4)) * ld + jb * 16 + (lane & 15)); };
@@ -259,26 +292,40 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
             else *dst = t[i];
         }
     };
-    bool dead = false;                                           // a poll gave up: finish without waiting (the update is marked failed)
-    unsigned long long seen = 0;
+    bool dead = false;                                           // a wait gave up: finish without waiting (the update is marked failed)
+    int seen = *(volatile lds_int_t*)&avail;                     // panels known to be out
     auto await = [&](int jb) {                                   // panel jb of block k is out
-        const unsigned long long want = pb + jb + 1;
-        if (dead || seen >= want) return;
-        for (int i = 0; i < POLL_SPINS; ++i) {
-            seen = ld_word(sig + SIGW_PANEL);
-            if (seen >= want) {
-                asm volatile("" ::: "memory");
-                return;
+        if (dead || seen > jb) return;
+        if (wave == 0) {
+            for (int i = 0; i < POLL_SPINS; ++i) {
+                seen = panels_out(ld_word(sig + SIGW_PANEL));
+                if (seen > jb) {
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) *(volatile lds_int_t*)&avail = seen;
+                    return;
+                }
+                if ((i & 1023) == 1023 && ld_info(info) == INT_MIN) break;
+                __builtin_amdgcn_s_sleep(crit ? 1 : 8);
             }
-            if ((i & 1023) == 1023 && ld_info(info) == INT_MIN) break;
-            __builtin_amdgcn_s_sleep(1);
+            dead = true;
+            if (lane == 0) {
+                st_info(info, INT_MIN);
+                *(volatile lds_int_t*)&avail = 99;               // (releases wave 1)
+            }
+        } else {
+            for (int i = 0; i < (POLL_SPINS << 3); ++i) {
+                seen = *(volatile lds_int_t*)&avail;
+                if (seen > jb) {
+                    asm volatile("" ::: "memory");
+                    if (seen > 8) dead = true;
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            dead = true;
         }
-        dead = true;
-        if (lane == 0) st_info(info, INT_MIN);
     };
-    seen = ld_word(sig + SIGW_PANEL);
-    asm volatile("" ::: "memory");
-    const bool late = seen >= pb + 8;                            // the whole diagonal block is out already
+    const bool late = seen >= 8;                                 // the whole diagonal block is out already
 #ifdef BOSS_CHAIN_TRACE
     if (crit && blockIdx.x == 0 && threadIdx.x == 0) g_ctrace[(k & 63) * 16 + 7] = late ? 1 : 0;
     if (crit && blockIdx.x == 0 && threadIdx.x == 0) g_ctrace[(k & 63) * 16 + 8] = __builtin_amdgcn_s_memrealtime();
@@ -353,6 +400,8 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (lane == 0) *(volatile lds_int_t*)&drained = 1;   // wave 1 may now raise the strip's word beyond TRSM_NA
         }
+#pragma unroll 1
+        for (int jb = TRSM_NA; jb < 8; ++jb) await(jb);          // (wave 1 learns of the remaining panels through this wave)
     } else {
         constexpr int NB = 8 - TRSM_NA;
         v4d acc[NB];
@@ -461,16 +510,16 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_follow_kernel(double* __re
     __builtin_amdgcn_s_setprio(3);
     CTRACE_MIN(k, 5);
     __shared__ v4d xs[TRSM_NA][64];
-    __shared__ int ready, drained;
+    __shared__ int ready, drained, avail;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* Brow = A + (size_t)row0 + (size_t)blockIdx.x * 16 + (size_t)k * BLK * ld;
-    follow_strip<false>(A, ld, k, inv16base, Brow, nullptr, sig, base, info, xs, ready, drained);
+    follow_strip<false>(A, ld, k, inv16base, Brow, nullptr, sig, base, info, xs, ready, drained, avail);
     if (blockIdx.x == 0 && wave == 0 && wait_rows) {
         // block row k+1 (solved by the resident strips) is out: the column update enqueued behind this kernel reads it
         const int lane = threadIdx.x & 63;
         for (int it = 0; it < POLL_SPINS; ++it) {
             unsigned long long v = ~0ull;
-            if (lane < 8) v = ld_word(sig + SIGW_PROG + lane);
+            if (lane < 8) v = ld_word(sig + SIGW_PROG + SIGW_PROG_STRIDE * lane);
             if (__all(v >= base + 8ull * k + 8)) break;
             if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
             if (it == POLL_SPINS - 1 && lane == 0) st_info(info, INT_MIN);
@@ -489,7 +538,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __re
                                                                     unsigned long long cbase, int* __restrict__ info) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ v4d xs[TRSM_NA][64];
-    __shared__ int ready, drained;
+    __shared__ int ready, drained, avail;
     const int lane = threadIdx.x & 63;
     for (int k = 0; k + 1 < nblk; ++k) {
         // tile (k+1, k) carries every panel < k
@@ -499,11 +548,28 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __re
         (void)ok;                                                // (gave up: info is marked, carry on without waiting — every loop stays bounded)
         __syncthreads();                                         // xs / ready / drained of the previous step are no longer in use
         double* Brow = A + (size_t)(k + 1) * BLK + (size_t)blockIdx.x * 16 + (size_t)k * BLK * ld;
-        follow_strip<true>(A, ld, k, inv16base, Brow, sig + SIGW_PROG + blockIdx.x, sig, base, info, xs, ready, drained);
+        follow_strip<true>(A, ld, k, inv16base, Brow, sig + SIGW_PROG + SIGW_PROG_STRIDE * blockIdx.x, sig, base, info, xs, ready, drained, avail);
 #ifdef BOSS_CHAIN_TRACE
         if (blockIdx.x == 0 && threadIdx.x == 64) g_ctrace[(k & 63) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
+}
+
+// Start-up probe (ctx_init): the chain schedule needs kernels of FOUR streams to run at the same time.  HIP maps streams to a
+// limited number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and kernels of two streams that share a queue run one
+// after the other — the resident kernels would wait for a kernel that is queued behind them.  One waiting lane per stream, released
+// by a kernel of the main stream: a waiter that times out (≈20 ms) means its stream cannot run beside the main stream.
+__global__ __launch_bounds__(64) void chain_probe_wait_kernel(unsigned long long* __restrict__ word, unsigned long long v,
+                                                              int* __restrict__ ok) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < (1 << 15); ++i) {
+        if (ld_word(word) >= v) {
+            *ok = 1;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    *ok = 0;
 }
 
 }  // namespace boss

@@ -150,7 +150,8 @@ __device__ __forceinline__ void raise_word(unsigned long long* w, unsigned long 
     __hip_atomic_store(as_global(w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // word indices inside the context's signal block (each group on a 128-byte line of its own)
-constexpr int SIGW_GATE = 0, SIGW_BULK = 3, SIGW_PANEL = 16, SIGW_WDONE = 32, SIGW_PROG = 48, SIGW_CRIT = 64, SIG_WORDS = 80;
+constexpr int SIGW_GATE = 0, SIGW_BULK = 3, SIGW_PANEL = 16, SIGW_WDONE = 32, SIGW_CRIT = 48, SIGW_NEAR = 8, SIGW_PROG = 64, SIGW_PROG_STRIDE = 16,
+              SIG_WORDS = SIGW_PROG + 8 * SIGW_PROG_STRIDE;   // (the eight strips' progress words: a line each — eight CUs store them, one wave polls all)
 constexpr int POLL_SPINS = 1 << 20;                        // ≈ 1 s: something lets only one kernel run at a time -> info = INT_MIN, the host falls back
 // One wave waits until *w >= v (wave-uniform).  false: gave up (timeout, or another waiter already marked the factorisation).
 __device__ __forceinline__ bool poll_ge(const unsigned long long* w, unsigned long long v, int* info) {
@@ -447,21 +448,29 @@ __global__ __launch_bounds__(64) void potrf_gate_kernel(unsigned long long* __re
 __global__ __launch_bounds__(64) void potrf_publish_kernel(unsigned long long* __restrict__ word, unsigned long long v) {
     if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Every wave of the waiting kernel calls this before it touches the operands (wave-uniform; w == nullptr: nothing to wait for).
-// Normally the word is already there: one load.  A wave that had to wait re-acquires (its kernel started before the producer ended).
+// Every thread of the waiting kernel calls this before it touches the operands (w == nullptr: nothing to wait for).
+// Normally the word is already there: one load.  ONE thread per workgroup polls, sleeping ≈0.4 µs between polls — with the
+// resident chain the column updates arrive early and wait tens of microseconds, and a thousand waves polling one line in memory
+// slowed the bulk update they were waiting for; the others wait at the barrier.  A workgroup that had to wait re-acquires (its
+// kernel started before the producer ended).
 __device__ __forceinline__ void wait_word(unsigned long long* w, unsigned long long v, int* info) {
     if (!w) return;
-    bool ok = false, waited = false;
-    for (int i = 0; i < (1 << 21); ++i) {
-        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) {
-            ok = true;
-            break;
+    __shared__ int waited_s;
+    if (threadIdx.x == 0) {
+        bool ok = false, waited = false;
+        for (int i = 0; i < (1 << 21); ++i) {
+            if (ld_word(w) >= v) {
+                ok = true;
+                break;
+            }
+            waited = true;
+            __builtin_amdgcn_s_sleep(16);
         }
-        waited = true;
-        __builtin_amdgcn_s_sleep(2);
+        if (!ok) st_info(info, INT_MIN);
+        *(volatile lds_int_t*)&waited_s = waited ? 1 : 0;
     }
-    if (!ok && (threadIdx.x & 63) == 0) info[0] = INT_MIN;
-    if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    if (*(volatile lds_int_t*)&waited_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // sig / sigval: when sig is non-null the kernel stores sigval there at its entry — every earlier kernel of its stream has

@@ -44,6 +44,9 @@ def main():
     pt = cu_all[256:].reshape(64, 4, 8)
     nblk = (N + 255) // 256 * 2
     vals = [int(v) for v in ch[:nblk, [0, 1, 2, 3, 4, 5, 8, 9, 10]].ravel() if 0 < int(v) < 2**63]
+    if not vals:
+        print('no stamps: the update did not run on the resident chain (fallback?)', api.last_error() if hasattr(api, 'last_error') else '')
+        return
     t0 = min(vals)
     us = lambda v: "       " if not (0 < int(v) < 2**63) else f"{(int(v) - t0) / 100.0:7.1f}"
     print(f"N={N}: update {dt * 1e3:.3f} ms (host); µs from the first stamp")
@@ -54,6 +57,11 @@ def main():
         per = "" if prev is None or not r[4] else f"{(int(r[4]) - prev) / 100.0:6.1f}"
         prev = int(r[4]) if r[4] else prev
         print(f"{k:2d} | {us(r[0])} {us(r[1])} {us(r[2])} {us(r[3])} {us(r[4])} |  {us(r[8])}  {int(r[7])}  {us(r[10])} | {us(r[5])} {us(r[9])} | {us(cu[k][0])} {us(cu[k][1])} | {per}")
+    print("boundary detail (µs after the previous block's C end): strips end, F sees last panel, operands landed, tiles written, C start")
+    for k in range(max(2, nblk - 6), nblk):
+        e = int(ch[k - 1][4])
+        g = lambda v: f"{(int(v) - e) / 100.0:6.2f}" if int(v) else "      "
+        print(f"  block {k:2d}: {g(ch[k - 1][10])} {g(ch[k][2])} {g(ch[k][11])} {g(ch[k][12])} {g(ch[k][3])}")
     panels(pt, t0, [nblk - 4, nblk - 3])
 
 
