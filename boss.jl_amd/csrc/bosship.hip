@@ -175,16 +175,18 @@ static int ctx_init(Ctx* c) {
         if (c->chain_ok) {
             // can kernels of the side, chain and strip streams run beside one of the main stream?  (see chain_probe_wait_kernel)
             int* okw = nullptr;
-            HIPCHK(hipMalloc((void**)&okw, 3 * sizeof(int)));
-            HIPCHK(hipMemset(okw, 0, 3 * sizeof(int)));
-            hipStream_t waiters[3] = {c->side_stream, c->chain_stream, c->strip_stream};
-            for (int i = 0; i < 3; ++i)
-                hipLaunchKernelGGL(chain_probe_wait_kernel, dim3(1), dim3(64), 0, waiters[i], c->sig_panel + SIGW_NEAR + 1, 1ull, okw + i);
-            hipLaunchKernelGGL(potrf_publish_kernel, dim3(1), dim3(64), 0, c->own_stream, c->sig_panel + SIGW_NEAR + 1, 1ull);
-            int okh[3] = {0, 0, 0};
+            HIPCHK(hipMalloc((void**)&okw, 4 * sizeof(int)));
+            HIPCHK(hipMemset(okw, 0, 4 * sizeof(int)));
+            hipStream_t probed[4] = {c->own_stream, c->side_stream, c->chain_stream, c->strip_stream};
+            for (int i = 0; i < 4; ++i)
+                hipLaunchKernelGGL(chain_probe_wait_kernel, dim3(1), dim3(64), 0, probed[i], c->sig_panel + SIGW_NEAR + 1, 4ull, okw + i);
+            int okh[4] = {0, 0, 0, 0};
             bool fine = hipDeviceSynchronize() == hipSuccess && hipMemcpy(okh, okw, sizeof okh, hipMemcpyDeviceToHost) == hipSuccess;
             (void)hipFree(okw);
-            if (!(fine && okh[0] && okh[1] && okh[2])) c->chain_ok = false;
+            if (!(fine && okh[0] && okh[1] && okh[2] && okh[3])) c->chain_ok = false;
+            if (getenv("BOSS_CHAIN_VERBOSE"))
+                std::fprintf(stderr, "[bosship] resident chain: %s (main / side / chain / strip streams side by side: %d %d %d %d)\n",
+                             c->chain_ok ? "on" : "off", okh[0], okh[1], okh[2], okh[3]);
         }
     }
     HIPCHK(hipHostMalloc(&c->pinned, PINNED_BYTES, hipHostMallocDefault));   // [0, 4 KiB) epilogue results, then staging (see temp_cand)

@@ -111,6 +111,7 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
         if (seen < 8) {
             if (lane == 0) {
                 st_info(info, INT_MIN);
+                note_giveup(4, b);
                 *seenw = 99;
             }
         }
@@ -310,6 +311,7 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
             dead = true;
             if (lane == 0) {
                 st_info(info, INT_MIN);
+                note_giveup(crit ? 5 : 6, k);
                 *(volatile lds_int_t*)&avail = 99;               // (releases wave 1)
             }
         } else {
@@ -522,7 +524,10 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_follow_kernel(double* __re
             if (lane < 8) v = ld_word(sig + SIGW_PROG + SIGW_PROG_STRIDE * lane);
             if (__all(v >= base + 8ull * k + 8)) break;
             if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
-            if (it == POLL_SPINS - 1 && lane == 0) st_info(info, INT_MIN);
+            if (it == POLL_SPINS - 1 && lane == 0) {
+                st_info(info, INT_MIN);
+                note_giveup(7, k);
+            }
             __builtin_amdgcn_s_sleep(4);
         }
     }
@@ -555,15 +560,17 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __re
     }
 }
 
-// Start-up probe (ctx_init): the chain schedule needs kernels of FOUR streams to run at the same time.  HIP maps streams to a
-// limited number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and kernels of two streams that share a queue run one
-// after the other — the resident kernels would wait for a kernel that is queued behind them.  One waiting lane per stream, released
-// by a kernel of the main stream: a waiter that times out (≈20 ms) means its stream cannot run beside the main stream.
-__global__ __launch_bounds__(64) void chain_probe_wait_kernel(unsigned long long* __restrict__ word, unsigned long long v,
+// Start-up probe (ctx_init): the chain schedule needs kernels of its four streams to run at the same time.  HIP maps streams to
+// a limited number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and kernels of two streams that share a queue run one
+// after the other — the resident kernels would wait for a kernel that is queued behind them (a fifth stream did exactly that).
+// One lane per stream, the main stream included: each counts itself in and waits until all have (≈20 ms at most); a lane that
+// never sees the full count means its stream cannot run beside the others, and the chain schedule stays off.
+__global__ __launch_bounds__(64) void chain_probe_wait_kernel(unsigned long long* __restrict__ word, unsigned long long want,
                                                               int* __restrict__ ok) {
     if (threadIdx.x != 0) return;
+    __hip_atomic_fetch_add(as_global(word), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = 0; i < (1 << 15); ++i) {
-        if (ld_word(word) >= v) {
+        if (ld_word(word) >= want) {
             *ok = 1;
             return;
         }

@@ -152,6 +152,9 @@ __device__ __forceinline__ void raise_word(unsigned long long* w, unsigned long 
 // word indices inside the context's signal block (each group on a 128-byte line of its own)
 constexpr int SIGW_GATE = 0, SIGW_BULK = 3, SIGW_PANEL = 16, SIGW_WDONE = 32, SIGW_CRIT = 48, SIGW_NEAR = 8, SIGW_PROG = 64, SIGW_PROG_STRIDE = 16,
               SIG_WORDS = SIGW_PROG + 8 * SIGW_PROG_STRIDE;   // (the eight strips' progress words: a line each — eight CUs store them, one wave polls all)
+// who gave up first (diagnostics: BOSS_CHAIN_VERBOSE prints it when an update falls back): code * 1000 + detail
+__device__ int g_giveup = 0;
+__device__ __forceinline__ void note_giveup(int code, int detail) { atomicCAS(&g_giveup, 0, code * 1000 + (detail & 511)); }
 constexpr int POLL_SPINS = 1 << 20;                        // ≈ 1 s: something lets only one kernel run at a time -> info = INT_MIN, the host falls back
 // One wave waits until *w >= v (wave-uniform).  false: gave up (timeout, or another waiter already marked the factorisation).
 __device__ __forceinline__ bool poll_ge(const unsigned long long* w, unsigned long long v, int* info) {
@@ -163,7 +166,10 @@ __device__ __forceinline__ bool poll_ge(const unsigned long long* w, unsigned lo
         if ((i & 1023) == 1023 && ld_info(info) == INT_MIN) return false;
         __builtin_amdgcn_s_sleep(1);
     }
-    if ((threadIdx.x & 63) == 0) st_info(info, INT_MIN);
+    if ((threadIdx.x & 63) == 0) {
+        st_info(info, INT_MIN);
+        note_giveup(1, (int)(v & 511));
+    }
     return false;
 }
 
@@ -439,6 +445,7 @@ __global__ __launch_bounds__(64) void potrf_gate_kernel(unsigned long long* __re
         __builtin_amdgcn_s_sleep(16);
     }
     info[0] = INT_MIN;
+    note_giveup(3, (int)(v & 511));
 }
 
 // The opposite direction (side stream -> chain): a one-lane kernel enqueued right behind the bulk update stores the next sequence
@@ -466,7 +473,10 @@ __device__ __forceinline__ void wait_word(unsigned long long* w, unsigned long l
             waited = true;
             __builtin_amdgcn_s_sleep(16);
         }
-        if (!ok) st_info(info, INT_MIN);
+        if (!ok) {
+            st_info(info, INT_MIN);
+            note_giveup(2, (int)(v & 511));
+        }
         *(volatile lds_int_t*)&waited_s = waited ? 1 : 0;
     }
     __syncthreads();
