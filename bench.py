@@ -144,8 +144,34 @@ def cpu_baseline(X, y, Xs, lam):
         t0 = time.perf_counter()
         O.ei_acquisition([post], Xs[:, :n_batched], [1.0], None, b)
         t_b = (time.perf_counter() - t0) / n_batched
+        # LAPACK dpotrf called directly, in place on a Fortran-ordered buffer (no copy, no zeroing of the other triangle) — what
+        # Julia's cholesky! does — and a dgemm of the same size as a health check of the BLAS on this host
+        from scipy.linalg.lapack import dpotrf
+        from scipy.linalg.blas import dgemm
+        Kf = np.asfortranarray(O.kernelmatrix_blas(post.h, X))
+        Kf[np.diag_indices(N_OBS)] += 0.05 ** 2
+        t_po = []
+        for _ in range(3):
+            a = Kf.copy(order="F")
+            t0 = time.perf_counter()
+            _, info_po = dpotrf(a, lower=1, overwrite_a=1, clean=0)
+            t_po.append(time.perf_counter() - t0)
+        t_potrf = min(t_po)
+        Bf = np.asfortranarray(Kf[:, :2048])
+        dgemm(1.0, Kf, Bf)
+        t0 = time.perf_counter()
+        dgemm(1.0, Kf, Bf)
+        t_gemm = time.perf_counter() - t0
+        gf_potrf = N_OBS ** 3 / 3 / t_potrf / 1e9
+        gf_gemm = 2.0 * N_OBS * N_OBS * 2048 / t_gemm / 1e9
+        note = (f"dpotrf in place {gf_potrf:.0f} GF/s, dgemm {gf_gemm:.0f} GF/s on {cores} BLAS threads "
+                f"({phys} cores in this container's CPU quota, {os.cpu_count()} logical CPUs on the host)")
+        if gf_potrf < 60:
+            note += ("; dpotrf far below the dgemm rate: OpenBLAS's blocked dpotrf is latency-bound on its panel factorisations when its "
+                     "threads are time-sliced inside a cgroup quota (the probe above already picked the fastest thread count)")
     return {
         "value": 1.0 / t_upd, "unit": "updates/s", "cores": int(cores), "kind": "port",
+        "dpotrf_inplace_ms": t_potrf * 1e3, "dpotrf_gflops": gf_potrf, "dgemm_gflops": gf_gemm, "blas_note": note,
         "sample": f"{reps} posterior updates at N={N_OBS} (BLAS-3 Gram + dpotrf + 2 dtrsv); {n_faithful} per-candidate (dtrsv) and "
                   f"{n_batched} batched (dtrsm) acquisition evals",
         "ms_per_update": t_upd * 1e3,
@@ -153,6 +179,68 @@ def cpu_baseline(X, y, Xs, lam):
         "acq_evals_per_sec_reference_pattern": 1.0 / t_f, "acq_evals_per_sec_batched": 1.0 / t_b,
         "blas_threads": int(cores), "physical_cores_available": int(phys), "host_cpu_count": os.cpu_count(),
     }
+
+
+def visible_gpus():
+    """Number of GPUs this process may use, without initialising HIP: the visibility variables, else the KFD topology."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                props = open(os.path.join(base, node, "properties")).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        pass
+    if n == 0:                                             # last resort (counts devices through the runtime)
+        import torch
+        n = torch.cuda.device_count()
+    return n
+
+
+def inproc_child(G, steps, warmup):
+    """`--inproc-child G` (a fresh process): BASELINE configs[2] through the ONE-PROCESS multi-GPU entry points a Julia caller
+    uses — boss_init, boss_multi_gp_update (the posterior replicated on G devices), boss_multi_acq_ei (8192 candidates split
+    M/G, arg-max exchange inside the library).  Prints one JSON object."""
+    import __graft_entry__ as entry
+    entry.compile_library()
+    from boss_jl_amd import api
+    api.load_library()
+    n = api.init()
+    G = max(1, min(G, n))
+    X, y, Xs = problem(1)
+    lam = np.full(D, 0.5)
+    reps = [api.GP(X, y, KERNEL, device=g) for g in range(G)]
+    best = float(y.max())
+    handles = [[[r]] for r in reps]
+    t_u = t_a = 0.0
+    am = mx = None
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        api.multi_update(reps, lam, 1.0, 0.05 + 1e-4 * (i % 7))
+        t1 = time.perf_counter()
+        _, am, mx = api.multi_acq_ei(handles, Xs, [1.0], None, best, want_acq=False)
+        t2 = time.perf_counter()
+        if i >= warmup:
+            t_u += t1 - t0
+            t_a += t2 - t1
+    ndev, rccl = api.comm_info()
+    print(json.dumps({"scaling": "strong", "driver": "one process, boss_init + boss_multi_gp_update + boss_multi_acq_ei (csrc/host_multi.inc)",
+                      "n_gpus": G, "devices_opened": ndev, "exchange": "rccl" if rccl and G > 1 else ("host" if G > 1 else "none"),
+                      "value": steps * M_CAND / t_a, "unit": "evals/s", "ms_acq_incl_exchange": t_a / steps * 1e3,
+                      "ms_update_replicated": t_u / steps * 1e3, "steps_per_sec": steps / (t_u + t_a),
+                      "argmax": [int(am), float(mx)], "steps": steps}), flush=True)
+    for r in reps:
+        r.close()
+    api.shutdown()
 
 
 def _free_port():
@@ -168,8 +256,7 @@ def launch_children(args):
     touches the GPU (a process that initialised the GPU must never be replaced or re-executed).  With fewer visible
     GPUs than ranks the children share device 0 and exchange over gloo (a rehearsal of the N>1 path on a 1-GPU box:
     marked `rehearsal` in the output, at most 6 processes per GPU)."""
-    import torch
-    n_vis = torch.cuda.device_count()                      # does not initialise the GPU
+    n_vis = visible_gpus()                                 # (no HIP call: the launcher must not count as a GPU process)
     if n_vis < 1:
         raise SystemExit("bench.py needs a GPU (bosship has no CPU fallback)")
     env = dict(os.environ)
@@ -182,16 +269,29 @@ def launch_children(args):
     entry.compile_library()                                # once, here (hipcc only: nothing is loaded, no GPU call)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus))
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out.decode())
+        procs.append(subprocess.Popen(cmd, env=e, stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # all ranks are watched: when one dies the others would sit in a collective until the distributed timeout
+    rc = 0
+    alive = set(range(args.gpus))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     raise SystemExit(rc)
 
@@ -203,7 +303,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the next_rows measurements (counter-collection passes)")
+    ap.add_argument("--inproc-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.inproc_child:
+        inproc_child(args.inproc_child, args.steps, args.warmup)
+        return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_children(args)                                  # does not return
@@ -431,6 +536,71 @@ def main():
                                  "predict_tflops": float(na) ** 2 * M_CAND / t_gp / 1e12}
         gg.close()
 
+    # ---- what DESIGN.md claims beyond the single-matrix chain, in the driver's own record (rank 0; N=1 only for the device work)
+    batched = acq_by_m = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        batched = {}
+        rs = np.random.default_rng(4)
+        for S in (8, 32):                                              # boss_gp_loglike_batch at N=4096: S hyper-parameter sets per call
+            lamS = np.exp(rs.normal(-0.7, 0.3, (D, S)))
+            ampS, sigS = np.exp(rs.normal(0.0, 0.3, S)), np.exp(rs.normal(-3.0, 0.3, S))
+            api.loglike_batch(X, y, KERNEL, lamS, ampS, sigS, device=dev)
+            t0 = time.perf_counter()
+            nrep = 3
+            for _ in range(nrep):
+                ll, st = api.loglike_batch(X, y, KERNEL, lamS, ampS, sigS, device=dev)
+            dt = (time.perf_counter() - t0) / nrep
+            batched[f"N4096_S{S}"] = {"updates_per_sec": S / dt, "ms_per_call": dt * 1e3, "tflops": S * flops_update(N_OBS, D) / dt / 1e12,
+                                      "frac_of_fp64_mfma_peak": S * flops_update(N_OBS, D) / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                      "all_positive_definite": bool((st == 0).all())}
+        N5, S5 = 1024, 512                                             # BASELINE configs[4]: 512 hyper-parameter samples, N=1024 each
+        X5 = rs.uniform(0, 1, (D, N5))
+        y5 = np.sin(2 * np.pi * X5).sum(0) / np.sqrt(D) + 0.05 * rs.standard_normal(N5)
+        lam5 = np.exp(rs.normal(-0.7, 0.3, (D, S5)))
+        amp5, sig5 = np.exp(rs.normal(0.0, 0.3, S5)), np.exp(rs.normal(-3.0, 0.3, S5))
+        api.loglike_batch(X5, y5, KERNEL, lam5, amp5, sig5, device=dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ll5, st5 = api.loglike_batch(X5, y5, KERNEL, lam5, amp5, sig5, device=dev)
+        dt = (time.perf_counter() - t0) / 3
+        batched["config5_512xN1024"] = {"factorisations_per_sec": S5 / dt, "ms_per_call": dt * 1e3, "tflops": S5 * flops_update(N5, D) / dt / 1e12,
+                                        "frac_of_fp64_mfma_peak": S5 * flops_update(N5, D) / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                        "all_positive_definite": bool((st5 == 0).all())}
+        # acquisition over M candidates of the N=4096 posterior: the first call on a fresh factorisation (what one step of a BO
+        # loop or one shard of configs[2] at G = 8192/M GPUs pays) and a later call on the same factorisation
+        acq_by_m = {}
+        for M in (1024, 2048, 4096, 8192):
+            cm = api.Candidates(Xs[:, :M], device=dev)
+            first, later = [], []
+            for i in range(4):
+                gp.update(lam, 1.0, 0.05 + 1e-4 * i)
+                t0 = time.perf_counter()
+                api.acq_ei([[gp]], cm, [1.0], None, best, want_acq=False)
+                first.append(time.perf_counter() - t0)
+                api.acq_ei([[gp]], cm, [1.0], None, best, want_acq=False)
+                t0 = time.perf_counter()
+                api.acq_ei([[gp]], cm, [1.0], None, best, want_acq=False)
+                later.append(time.perf_counter() - t0)
+            tf, tl = float(np.median(first[1:])), float(np.median(later[1:]))
+            fl = M * flops_acq_eval(N_OBS, D)
+            acq_by_m[str(M)] = {"first_call_ms": tf * 1e3, "first_call_evals_per_sec": M / tf, "first_call_frac_of_peak": fl / tf / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                "later_call_ms": tl * 1e3, "later_call_evals_per_sec": M / tl, "later_call_frac_of_peak": fl / tl / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                "path_first_call": "fused kernel (one workgroup per 32 candidates)" if M > 4096 else
+                                                   "256-row substitution steps spread over the chip (few-candidates path)",
+                                "path_later_calls": "fused kernel" if M > 4096 else "resident inverse factors (two GEMMs, built on the second call)"}
+            cm.close()
+
+    # ---- configs[2] through the one-process multi-GPU entry points (a fresh child process: this one stays alive and idle meanwhile)
+    inproc = None
+    if rank == 0 and not args.no_extras:
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inproc-child", str(world), "--steps", str(args.steps),
+                                "--warmup", str(args.warmup)], env=env, capture_output=True, text=True, timeout=600)
+            inproc = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:                                         # never fails the bench line
+            inproc = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(X, y, Xs, lam)
@@ -453,7 +623,8 @@ def main():
                        "parallelism": f"{world} independent GP slices + candidate shards, 16-byte arg-max all-gather over {backend}"},
             "frac_of_fp64_mfma_roofline": {"update": flops_update(N_OBS, D) * upd_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12),
                                            "acq": flops_acq_eval(N_OBS, D) * acq_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12)},
-            "roofline": roof, "roofline_potrf": roof_potrf, "strong_scaling": strong, "cpu_baseline": cpu, "next_rows": extras,
+            "roofline": roof, "roofline_potrf": roof_potrf, "strong_scaling": strong, "strong_scaling_inproc": inproc,
+            "batched_updates": batched, "acq_by_M": acq_by_m, "cpu_baseline": cpu, "next_rows": extras,
         }
         if os.environ.get("BOSS_BENCH_REHEARSAL"):
             out["rehearsal"] = f"{world} ranks share {n_vis} GPU(s), exchange over gloo — a functional rehearsal of the N>1 path, not a scaling measurement"

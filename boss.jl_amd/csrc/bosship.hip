@@ -72,7 +72,8 @@ struct Workspace {
 };
 
 struct Ctx {
-    int device = -1;
+    int device = -1;                            // the physical HIP device (hipSetDevice)
+    int logical = -1;                           // the index the ABI knows it by (== device unless BOSS_VIRTUAL_DEVICES is set)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // trailing updates of the look-ahead Cholesky
@@ -223,20 +224,37 @@ static int ctx_init(Ctx* c) {
     return BOSS_OK;
 }
 
+// BOSS_VIRTUAL_DEVICES=n: the ABI shows n devices, device i being a context of its own (streams, workspaces, handles) on physical
+// device i mod (number of physical devices).  The one-process multi-device entry points (host_multi.inc) can then be run with
+// G > 1 on a one-GPU box — RCCL refuses a communicator with one device twice, so their exchanges take the host path there.
+static int virtual_devices() {
+    static const int v = getenv("BOSS_VIRTUAL_DEVICES") ? std::max(0, atoi(getenv("BOSS_VIRTUAL_DEVICES"))) : 0;
+    return v;
+}
+static int visible_devices(int* nphys_out = nullptr) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    if (nphys_out) *nphys_out = n;
+    return virtual_devices() > 0 ? virtual_devices() : n;
+}
+
 static int get_ctx(int device, Ctx** out) {
     std::lock_guard<std::mutex> lk(g_ctx_mtx);
     auto it = g_ctx.find(device);
     if (it != g_ctx.end()) {
         *out = it->second;
-        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipSetDevice(it->second->device));
         return BOSS_OK;
     }
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BOSS_E_NO_DEVICE, "no HIP device visible (bosship has no CPU fallback)");
+    int nphys = 0;
+    const int n = visible_devices(&nphys);
+    if (n <= 0) return fail(BOSS_E_NO_DEVICE, "no HIP device visible (bosship has no CPU fallback)");
     if (device < 0 || device >= n) return fail(BOSS_E_INVALID, "device index out of range");
-    HIPCHK(hipSetDevice(device));
+    const int phys = device % nphys;
+    HIPCHK(hipSetDevice(phys));
     Ctx* c = new Ctx();
-    c->device = device;
+    c->device = phys;
+    c->logical = device;
     int rc = ctx_init(c);
     if (rc) {                                                // a half-built context does not stay behind
         ctx_destroy(c);
@@ -363,8 +381,8 @@ extern "C" const char* boss_version(void) { return "bosship 0.1.0 (gfx950, fp64 
 extern "C" const char* boss_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int boss_device_count(int* n_out) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
+    const int n = visible_devices();
+    hipError_t e = n > 0 ? hipSuccess : hipErrorNoDevice;
     if (e != hipSuccess || n <= 0) {
         if (n_out) *n_out = 0;
         return fail(BOSS_E_NO_DEVICE, "no HIP device visible (bosship has no CPU fallback)");

@@ -130,22 +130,138 @@ function data_loglike(m::HipGaussianProcess, data::BOSS.ExperimentData)
     end                                    # exceptions → -Inf via BOSS.safe_data_loglike, as for any model
 end
 
+# ---------------------------------------------------------------- Semiparametric (parametric mean + GP; BASELINE config 4)
+"BOSS.Semiparametric whose GP part lives on an MI355X: the parametric model is evaluated on the host into the mean vectors."
+struct HipSemiparametric{S<:BOSS.Semiparametric} <: BOSS.SurrogateModel
+    sp::S
+    device::Cint
+end
+HipSemiparametric(sp::BOSS.Semiparametric; device = 0) = HipSemiparametric(sp, Cint(device))
+
+"Own parameter type (same reason as `HipGPParams`): θ of the parametric mean, then the GP's λ, α, σ (semiparametric.jl:52-63)."
+struct HipSemiparametricParams{T<:AbstractVector{<:Real}, L<:AbstractMatrix{<:Real}, A<:AbstractVector{<:Real},
+                               N<:AbstractVector{<:Real}} <: BOSS.ModelParams{HipSemiparametric}
+    θ::T
+    λ::L
+    α::A
+    σ::N
+end
+to_sp(p::HipSemiparametricParams) = BOSS.SemiparametricParams(p.θ, p.λ, p.α, p.σ)
+to_hip(p::BOSS.SemiparametricParams) = HipSemiparametricParams(p.θ, p.λ, p.α, p.σ)
+gp_part(p::HipSemiparametricParams) = HipGPParams(p.λ, p.α, p.σ)                    # _extract_gp_params, semiparametric.jl:65-71
+
+# model API (src/types/surrogate_model.jl:19-73) delegated to the wrapped model, containers converted at the boundary
+params_loglike(m::HipSemiparametric) = (ll = params_loglike(m.sp); (p::HipSemiparametricParams) -> ll(to_sp(p)))
+_params_sampler(m::HipSemiparametric) = (sample = _params_sampler(m.sp); rng -> to_hip(sample(rng)))
+function vectorizer(m::HipSemiparametric)
+    vec_sp, devec_sp = vectorizer(m.sp)                    # θ, vec(λ), α, σ with the Dirac-prior entries left out (semiparametric.jl:114-144)
+    vectorize(p::HipSemiparametricParams) = vec_sp(to_sp(p))
+    devectorize(p::HipSemiparametricParams, ps::AbstractVector{<:Real}) = to_hip(devec_sp(to_sp(p), ps))
+    return vectorize, devectorize
+end
+bijector(m::HipSemiparametric) = bijector(m.sp)
+BOSS.param_priors(m::HipSemiparametric) = BOSS.param_priors(m.sp)
+BOSS.param_count(p::HipSemiparametricParams) = sum(BOSS.param_lengths(p))
+BOSS.param_lengths(p::HipSemiparametricParams) = (length(p.θ), length(p.λ), length(p.α), length(p.σ))
+BOSS.param_shapes(p::HipSemiparametricParams) = (size(p.θ), size(p.λ), size(p.α), size(p.σ))
+sliceable(::HipSemiparametric) = false                    # θ is shared by all outputs (as for BOSS.Semiparametric)
+make_discrete(m::HipSemiparametric, d::AbstractVector{Bool}) = HipSemiparametric(make_discrete(m.sp, d), m.device)
+
+"The GP of the semiparametric model under θ: the nonparametric part with the parametric prediction as its mean (semiparametric.jl:79-85)."
+hip_gp(m::HipSemiparametric, θ) = HipGaussianProcess(BOSS.add_mean(m.sp.nonparametric, m.sp.parametric(θ)), m.device)
+model_posterior_slice(m::HipSemiparametric, p::HipSemiparametricParams, data::BOSS.ExperimentData, i::Int) =
+    model_posterior_slice(hip_gp(m, p.θ), gp_part(p), data, i)   # a HipPosteriorSlice whose `mean` is x -> f(x; θ)[i]: mean_Xs follows from it
+
+function data_loglike(m::HipSemiparametric, data::BOSS.ExperimentData)
+    X = Matrix{Float64}(data.X); k = m.sp.nonparametric.kernel
+    hs = map(1:size(data.Y, 1)) do i                                   # resident data, one handle per output
+        h = Ref{Ptr{Cvoid}}()
+        check(ccall((:boss_gp_create, lib), Cint, (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+              m.device, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]), discrete_flags(k), h))
+        Handle(h[])
+    end
+    return function ll_data(p::HipSemiparametricParams)
+        f = m.sp.parametric(p.θ)                                       # semiparametric.jl:87-92: the mean changes with θ
+        F = reduce(hcat, (Float64.(f(x)) for x in eachcol(X)))         # y_dim × N, evaluated once per likelihood call
+        sum(eachindex(hs)) do i
+            lp = Ref{Cdouble}()
+            check(ccall((:boss_gp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Ref{Cdouble}),
+                  hs[i].h, Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], Vector{Float64}(F[i, :]), 0, lp))
+            lp[]
+        end
+    end
+end
+
+# ---------------------------------------------------------------- Bayesian inference (BASELINE config 5)
+# `BIParams` (src/types/parameters.jl:128-146) carries S parameter samples; `model_posterior(model, ::AbstractVector{<:ModelParams},
+# data)` (src/posterior.jl:15-19) broadcasts over them, so `BOSS.model_posterior(problem)` of a problem fitted with TuringBI
+# (ext/TuringExt.jl:88-107 — it only needs the model API above) is a Vector of posteriors = P×S device handles, and
+# `HipBatchAM` averages the acquisition over the S samples on the device (`boss_acq_ei(P, S, …)`).  The S factorisations of one
+# output share (X, y): `model_posteriors_batched` builds them from ONE upload per output instead of S.
+function model_posteriors_batched(m::HipGaussianProcess, ps::AbstractVector{<:HipGPParams}, data::BOSS.ExperimentData)
+    X = Matrix{Float64}(data.X); P = size(data.Y, 1)
+    slices = [Vector{HipPosteriorSlice}(undef, P) for _ in ps]
+    for i in 1:P
+        y = Vector{Float64}(data.Y[i, :]); mu = BOSS.mean_getindex(m.gp.mean, i); mv = mean_vals(mu, X)
+        for (s, p) in enumerate(ps)
+            h = Ref{Ptr{Cvoid}}(); lp = Ref{Cdouble}()
+            check(ccall((:boss_gp_fit, lib), Cint,
+                (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble,
+                 Ptr{UInt8}, Ref{Ptr{Cvoid}}, Ref{Cdouble}),
+                m.device, kernel_id(base_kernel(m.gp.kernel)), size(X, 1), size(X, 2), X, y, mv,
+                Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], discrete_flags(m.gp.kernel), h, lp))
+            slices[s][i] = HipPosteriorSlice(Handle(h[]), mu)
+        end
+    end
+    return [BOSS.DefaultModelPosterior(sl) for sl in slices]           # what model_posterior(problem) returns under BIParams
+end
+BOSS.model_posterior(m::HipGaussianProcess, ps::AbstractVector{<:HipGPParams}, data::BOSS.ExperimentData) =
+    model_posteriors_batched(m, ps, data)
+BOSS.model_posterior(m::HipSemiparametric, ps::AbstractVector{<:HipSemiparametricParams}, data::BOSS.ExperimentData) =
+    [BOSS.model_posterior(m, p, data) for p in ps]                     # θ differs per sample: a mean function per sample
+
+"Importance-resampled BI on the device: S candidates from the prior scored in ONE batched likelihood call, `samples` of them drawn
+with probability ∝ exp(loglike) — a cheap stand-in where Turing is not loaded; a TuringBI chain works unchanged with these models."
+Base.@kwdef struct HipImportanceBI <: BOSS.ModelFitter{BOSS.BIParams}
+    candidates::Int
+    samples::Int
+end
+function estimate_parameters(f::HipImportanceBI, problem::BOSS.BossProblem, options::BOSS.BossOptions)
+    all = estimate_parameters(HipBatchedMAP(samples = f.candidates), problem, options; return_all = true)
+    ll = Float64[p.loglike for p in all]; w = exp.(ll .- maximum(ll)); w ./= sum(w)
+    idx = [findfirst(>=(rand()), cumsum(w)) for _ in 1:f.samples]
+    return BOSS.BIParams(samples = [all[something(i, length(all))].params for i in idx])
+end
+
 # ---------------------------------------------------------------- ModelFitter (SamplingMAP semantics, batched)
 Base.@kwdef struct HipBatchedMAP <: BOSS.ModelFitter{BOSS.MAPParams}
     samples::Int
 end
+gp_kernel(m::HipGaussianProcess) = m.gp.kernel
+gp_kernel(m::HipSemiparametric) = m.sp.nonparametric.kernel
+"Prior means of output i at the data for every parameter sample: (pointer argument, stride) of boss_gp_loglike_batch."
+batch_means(m::HipGaussianProcess, ps, X, i) = (mean_vals(BOSS.mean_getindex(m.gp.mean, i), X), 0)      # one vector for all sets
+function batch_means(m::HipSemiparametric, ps, X, i)                                                   # S×N, row s = f(x_j; θ_s)[i]
+    F = Matrix{Float64}(undef, size(X, 2), length(ps))                 # column s contiguous = row s of the S×N row-major array
+    for (s, p) in enumerate(ps)
+        f = m.sp.parametric(p.θ)
+        F[:, s] .= (f(x)[i] for x in eachcol(X))
+    end
+    return F, size(X, 2)
+end
 function estimate_parameters(f::HipBatchedMAP, problem::BOSS.BossProblem, options::BOSS.BossOptions; return_all=false)
-    m = problem.model::HipGaussianProcess; data = problem.data
+    m = problem.model::Union{HipGaussianProcess, HipSemiparametric}; data = problem.data
     sampler = BOSS.params_sampler(m, data); prior = params_loglike(m)
     ps = [sampler() for _ in 1:f.samples]
-    X = Matrix{Float64}(data.X); ll = zeros(f.samples)
+    X = Matrix{Float64}(data.X); ll = zeros(f.samples); k = gp_kernel(m)
     for i in 1:size(data.Y, 1)
         λ = reduce(hcat, (p.λ[:, i] for p in ps)); lli = zeros(f.samples); st = zeros(Cint, f.samples)
+        mv, stride = batch_means(m, ps, X, i)
         check(ccall((:boss_gp_loglike_batch, lib), Cint,
             (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint,
              Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
-            m.device, kernel_id(base_kernel(m.gp.kernel)), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]),
-            mean_vals(BOSS.mean_getindex(m.gp.mean, i), X), 0, discrete_flags(m.gp.kernel), f.samples,
+            m.device, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]),
+            mv, stride, discrete_flags(k), f.samples,
             Matrix{Float64}(λ), Float64[p.α[i] for p in ps], Float64[p.σ[i] for p in ps], lli, st))
         ll .+= lli
     end

@@ -191,6 +191,21 @@ def test_integration_doc_shows_the_shipped_julia_glue():
     assert called and called <= syms, called - syms
     for must in ("boss_gp_fit", "boss_gp_update", "boss_gp_predict", "boss_acq_ei", "boss_multi_acq_ei", "boss_init", "boss_gp_loglike_batch"):
         assert must in called, must
+    # every method of the model API (/root/reference/src/types/surrogate_model.jl:19-73) is defined for BOTH device models:
+    # the plain GP (BASELINE configs 1-3, 5) and the semiparametric model (config 4), each with a parameter type of its own
+    for model, params in (("HipGaussianProcess", "HipGPParams"), ("HipSemiparametric", "HipSemiparametricParams")):
+        assert re.search(r"struct %s\b[^\n]*<: BOSS\.SurrogateModel" % model, jl), model
+        assert re.search(r"struct %s\{.{0,300}?\}\s*<: BOSS\.ModelParams\{%s\}" % (params, model), jl, re.S), params
+        for fn in ("model_posterior_slice", "data_loglike", "params_loglike", "_params_sampler", "vectorizer", "bijector", "make_discrete"):
+            assert re.search(r"(function )?%s\(m::%s[,)]" % (fn, model), jl), (fn, model)
+        assert re.search(r"sliceable\(::%s\)" % model, jl), model
+        for fn in ("param_count", "param_lengths", "param_shapes"):
+            assert re.search(r"BOSS\.%s\(p::%s\)" % (fn, params), jl), (fn, params)
+    for fn in ("slice(m::HipGaussianProcess", "slice(p::HipGPParams", "join_slices(ps::AbstractVector{<:HipGPParams}"):   # sliceable model
+        assert fn in jl, fn
+    # the parametric mean reaches the device as mean vectors (semiparametric.jl:79-92), the BI flow as P×S handles (posterior.jl:15-19)
+    assert "BOSS.add_mean(m.sp.nonparametric, m.sp.parametric(θ))" in jl and "batch_means(m::HipSemiparametric" in jl
+    assert "BOSS.model_posterior(m::HipGaussianProcess, ps::AbstractVector{<:HipGPParams}" in jl and "BOSS.BIParams(samples" in jl
     # every ccall passes as many arguments as its type tuple declares
     for m in re.finditer(r"ccall\(\(:(boss_[a-z0-9_]+), lib\), (\w+),\s*\(([^)]*)\)", jl, re.S):
         name, types = m.group(1), [t for t in m.group(3).replace("\n", " ").split(",") if t.strip()]

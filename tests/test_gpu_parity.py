@@ -758,6 +758,20 @@ def test_multi_device_entry_points(api, O):
     assert api.init() == n                                  # re-initialisation after a shutdown
 
 
+@pytest.mark.parametrize("G", [2, 3])
+def test_multi_device_entry_points_on_virtual_devices(G):
+    """csrc/host_multi.inc with G > 1 on the one-GPU test box: BOSS_VIRTUAL_DEVICES=G makes the library show G devices (contexts of
+    their own on the one physical GPU; exchanges through the host since RCCL refuses one device twice).  The worker runs the three
+    shard modes, the replicated update and the sharded likelihood batch against the single-device entry points and the oracle:
+    ragged M, the mean_Xs re-layout, owners on different devices, ties and NaN across shards, unfitted / misplaced replicas,
+    fewer hyper-parameter sets than devices (sampling.jl:43-57, posterior.jl:31-79)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_virtual_worker.py")],
+                       env=dict(os.environ, BOSS_VIRTUAL_DEVICES=str(G)), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and f"VIRTUAL-OK {G}" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("N0,steps", [(5, [1, 1, 3]), (100, [1]), (127, [2]), (128, [1]), (130, [1, 1, 1]), (255, [1, 130]),
                                       (300, [40, 100]), (256, [600]), (640, [1, 1]), (255, [33]), (250, [7, 300])])
 def test_block_cholesky_append(api, O, N0, steps):
