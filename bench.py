@@ -221,23 +221,30 @@ def inproc_child(G, steps, warmup):
     reps = [api.GP(X, y, KERNEL, device=g) for g in range(G)]
     best = float(y.max())
     handles = [[[r]] for r in reps]
+    mcand = api.MultiCandidates(Xs, G)                                # the candidate shards stay resident, as in the per-rank records
     t_u = t_a = 0.0
     am = mx = None
     for i in range(warmup + steps):
         t0 = time.perf_counter()
         api.multi_update(reps, lam, 1.0, 0.05 + 1e-4 * (i % 7))
         t1 = time.perf_counter()
-        _, am, mx = api.multi_acq_ei(handles, Xs, [1.0], None, best, want_acq=False)
+        _, am, mx = api.multi_acq_ei_cand(handles, mcand, [1.0], None, best, want_acq=False)
         t2 = time.perf_counter()
         if i >= warmup:
             t_u += t1 - t0
             t_a += t2 - t1
+    t0 = time.perf_counter()
+    for i in range(3):                                                # the same with candidates uploaded per call (boss_multi_acq_ei)
+        api.multi_acq_ei(handles, Xs, [1.0], None, best, want_acq=False)
+    t_oneshot = (time.perf_counter() - t0) / 3
     ndev, rccl = api.comm_info()
     print(json.dumps({"scaling": "strong", "driver": "one process, boss_init + boss_multi_gp_update + boss_multi_acq_ei (csrc/host_multi.inc)",
                       "n_gpus": G, "devices_opened": ndev, "exchange": "rccl" if rccl and G > 1 else ("host" if G > 1 else "none"),
                       "value": steps * M_CAND / t_a, "unit": "evals/s", "ms_acq_incl_exchange": t_a / steps * 1e3,
                       "ms_update_replicated": t_u / steps * 1e3, "steps_per_sec": steps / (t_u + t_a),
+                      "ms_acq_with_per_call_upload": t_oneshot * 1e3,
                       "argmax": [int(am), float(mx)], "steps": steps}), flush=True)
+    mcand.close()
     for r in reps:
         r.close()
     api.shutdown()

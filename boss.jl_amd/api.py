@@ -76,6 +76,10 @@ SIGNATURES = {
     "boss_multi_gp_update": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), _c_dp, C.c_double, C.c_double, _c_dp, _c_dp]),
     "boss_multi_acq_ei": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
                                     C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_multi_cand_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _c_dp, C.POINTER(C.c_void_p)]),
+    "boss_multi_cand_free": (None, [C.c_void_p]),
+    "boss_multi_acq_ei_cand": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, _c_dp, _c_dp, _c_dp, C.c_int,
+                                         C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
     "boss_multi_acq_ei_outputs": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
                                             C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
     "boss_multi_acq_ei_samples": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
@@ -708,6 +712,45 @@ def multi_acq_ei(replicas: Sequence[Sequence[Sequence[GP]]], Xs, fit_coefs, y_ma
     am, mx = C.c_long(-1), C.c_double(0.0)
     _check(load_library().boss_multi_acq_ei(G, P, S, arr, M, _dp(Xs), _dp(ms), _dp(coefs), _dp(ym), 0 if best is None else 1,
                                             0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am), C.byref(mx)))
+    return acq, am.value, mx.value
+
+
+class MultiCandidates:
+    """boss_multi_cand_create: candidates resident on G devices (shard g = the g-th balanced contiguous range of the columns)."""
+
+    def __init__(self, Xs, G: int):
+        Xs = _f64(Xs, 2)
+        self.d, self.M, self.G = Xs.shape[0], Xs.shape[1], int(G)
+        self._h = C.c_void_p()
+        _check(load_library().boss_multi_cand_create(self.G, self.d, self.M, _dp(Xs), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load_library().boss_multi_cand_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def multi_acq_ei_cand(replicas: Sequence[Sequence[Sequence[GP]]], cand: MultiCandidates, fit_coefs, y_max=None, best=None,
+                      valid_mask=None, mean_Xs=None, want_acq: bool = True):
+    """boss_multi_acq_ei_cand: multi_acq_ei on resident candidate shards.  Returns (acq[M] or None, argmax, max)."""
+    G, S, P = len(replicas), len(replicas[0]), len(replicas[0][0])
+    M = cand.M
+    arr = (C.c_void_p * (G * S * P))()
+    for g in range(G):
+        for s in range(S):
+            for p in range(P):
+                arr[p + P * (s + S * g)] = replicas[g][s][p]._h
+    coefs, ym, mask, ms = _acq_common(P, S, M, fit_coefs, y_max, valid_mask, mean_Xs)
+    acq = np.zeros(M) if want_acq else None
+    am, mx = C.c_long(-1), C.c_double(0.0)
+    _check(load_library().boss_multi_acq_ei_cand(G, P, S, arr, cand._h, _dp(ms), _dp(coefs), _dp(ym), 0 if best is None else 1,
+                                                 0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am), C.byref(mx)))
     return acq, am.value, mx.value
 
 

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(ACQ_EPI_THREADS) void acq_epilogue_kernel(const dou
                                                                        const double* __restrict__ ymax_dev,
                                                                        double* __restrict__ acq_sum, int have_prev,
                                                                        double inv_s, const unsigned char* __restrict__ mask,
-                                                                       double* __restrict__ res, unsigned long long res_seq) {
+                                                                       double* __restrict__ res, unsigned long long res_seq,
+                                                                       double* __restrict__ dpair = nullptr, long idx_off = 0) {
     __shared__ double sv[ACQ_EPI_THREADS];
     __shared__ long si[ACQ_EPI_THREADS];
     constexpr long NONE = 0x7fffffffffffffffL;
@@ -117,6 +118,10 @@ __global__ __launch_bounds__(ACQ_EPI_THREADS) void acq_epilogue_kernel(const dou
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        if (dpair) {                                         // one shard of a multi-device call: (max, GLOBAL index) for the all-gather
+            dpair[0] = sv[0];
+            dpair[1] = (double)(si[0] + idx_off);
+        }
         res[0] = sv[0];
         reinterpret_cast<long*>(res)[1] = si[0];
         if (res_seq) {                                       // res is mapped host memory and the host polls this word (boss_acq_ei)

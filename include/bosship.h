@@ -336,6 +336,15 @@ int boss_multi_acq_ei(int G, int P, int S, boss_gp_t* const* gps, int M, const d
  * owner predicts its (mu, var) rows for all M candidates; the rows travel in ONE RCCL all-reduce(sum) over zero-filled
  * blocks (exact), then the EI x feasibility epilogue and the arg-max run on the device of gps[0]
  * (expected_improvement.jl:68-90).  Arguments as boss_acq_ei with host candidates. */
+// Resident candidate shards for boss_multi_acq_ei_cand: shard g (the balanced contiguous range of get_sample_counts,
+// /root/reference/src/utils/sampling.jl:6-13) is uploaded to device g once; replaces the per-call `acq.(eachcol(xs))` operand of
+// /root/reference/src/acquisition_maximizers/sampling.jl:43-57 when several acquisition calls share their candidates.
+typedef struct boss_multi_cand boss_multi_cand_t;
+int boss_multi_cand_create(int G, int d, int M, const double* Xs /*d×M*/, boss_multi_cand_t** out);
+void boss_multi_cand_free(boss_multi_cand_t* cand);
+int boss_multi_acq_ei_cand(int G, int P, int S, boss_gp_t* const* gps /*[G][S][P]*/, const boss_multi_cand_t* cand,
+                           const double* mean_Xs /*P×M×S|NULL*/, const double* fit_coefs, const double* y_max, int has_best, double best,
+                           const unsigned char* valid_mask, double* acq_out, long* argmax_out, double* max_out);
 int boss_multi_acq_ei_outputs(int P, int S, boss_gp_t* const* gps, int M, const double* Xs, const double* mean_Xs,
                               const double* fit_coefs, const double* y_max, int has_best, double best,
                               const unsigned char* valid_mask, double* acq_out, long* argmax_out, double* max_out);

@@ -54,6 +54,18 @@ single = api.acq_ei(repl[0], cand0, coefs, y_max, b, mask, mS)
 assert np.allclose(acq, single[0], rtol=0, atol=1e-13) and (am, mx) == (single[1], single[2])
 _, am2, mx2 = api.multi_acq_ei(repl, Xs, coefs, y_max, b, mask, mS, want_acq=False)
 assert (am2, mx2) == (am, mx)
+# resident candidate shards: uploaded once, used by several calls
+mcand = api.MultiCandidates(Xs, G)
+for _ in range(2):
+    a_r, am_r, mx_r = api.multi_acq_ei_cand(repl, mcand, coefs, y_max, b, mask, mS)
+    assert np.array_equal(a_r, acq) and (am_r, mx_r) == (am, mx)
+_, am_r, mx_r = api.multi_acq_ei_cand(repl, mcand, coefs, y_max, b, mask, mS, want_acq=False)
+assert (am_r, mx_r) == (am, mx)
+mcand.close()
+# more devices than candidates: empty shards take no part
+a_e, am_e, mx_e = api.multi_acq_ei(repl, Xs[:, :1], coefs, y_max, b, None, mS[:, :, :1])
+assert am_e == 0 and abs(a_e[0] - O.ei_acquisition(posts[0], Xs[:, :1], coefs, y_max, b, means_s=[mS[0, 0, :1], mS[0, 1, :1]])[0] / S
+                         - sum(O.ei_acquisition(posts[s], Xs[:, :1], coefs, y_max, b, means_s=[mS[s, 0, :1], mS[s, 1, :1]])[0] for s in range(1, S)) / S) <= 1e-10
 # fewer devices than the communicator holds (a subset): still the same
 if G > 2:
     a2, am3, mx3 = api.multi_acq_ei(repl[:2], Xs, coefs, y_max, b, mask, mS)
