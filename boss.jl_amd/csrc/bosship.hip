@@ -195,6 +195,7 @@ static int ctx_init(Ctx* c) {
     // kernels that need more than 64 KiB of dynamic LDS
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_strips_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STRIPS_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_llgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LLG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));

@@ -36,6 +36,7 @@ __device__ unsigned long long g_ctrace[64 * 16];
 // 40-48 callee-saved registers through scratch on the step's critical path.  Cutting every live range at the phase boundary
 // costs one reload of the thread index per phase.
 #define CHAIN_CUT_VGPRS() asm volatile("" ::: "memory", "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119")   // (v120-v127 stay: SGPR spill lanes, the thread index)
+constexpr int STRIPS_LDS_BYTES = 90 * 1024;                  // occupancy limiter of potrf_strips_kernel (see chain_begin)
 constexpr int CHAIN_CTRL = DIAG_TILES * 256 + DIAG_STAGE;   // doubles: one control word behind the diagonal-block kernel's LDS
 constexpr int CHAIN_LDS_BYTES = (CHAIN_CTRL + 2) * 8;       // two control words (ints): go-ahead of the block, posted panel count
 
@@ -59,12 +60,11 @@ __device__ const unsigned char chain_tile_tab[16][3] = {   // wave -> tile row, 
     {7, 0, 3}, {7, 3, 3}, {7, 6, 2}, {6, 0, 3}, {6, 3, 2}, {6, 5, 2}, {5, 0, 3}, {5, 3, 3},
     {4, 0, 3}, {4, 3, 2}, {3, 0, 2}, {3, 2, 2}, {2, 0, 3}, {1, 0, 2}, {0, 0, 1}, {0, 0, 0}};
 __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int ld, int b, int* __restrict__ info,
-                                                             unsigned long long* __restrict__ sig, unsigned long long base) {
+                                                             unsigned long long* __restrict__ sig, unsigned long long base, int wave_s) {
     extern __shared__ double smem[];
-    int tok = 0;
-    asm volatile("" : "+v"(tok));                        // (opaque zero, as in chain_factor_phase)
-    const int tid = threadIdx.x + tok, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (as in chain_factor_phase)
+    asm volatile("" : "+v"(lane));
+    const int wave = wave_s, tid = wave * 64 + lane;
     const int r16 = lane & 15, q = lane >> 4;
     const int ti = chain_tile_tab[wave][0], tj0 = chain_tile_tab[wave][1], nt = chain_tile_tab[wave][2];
     constexpr int U = 3;
@@ -186,12 +186,15 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
 // C(b): the block in the LDS tile area is factored and published panel by panel.
 __device__ __forceinline__ void chain_factor_phase(double* __restrict__ Ab, int ld, double* __restrict__ inv16b, int col0,
                                                              unsigned long long* __restrict__ pubword, unsigned long long seq0,
-                                                             int* __restrict__ info) {
+                                                             int* __restrict__ info, int wave_s) {
     extern __shared__ double smem[];
     int fail = -1;
-    int tok = 0;
-    asm volatile("" : "+v"(tok));                        // (opaque zero: the per-lane offsets are recomputed per block, not hoisted and spilled)
-    diag_block_factor<false, false, true>(smem, Ab, ld, inv16b, col0, 8, fail, nullptr, pubword, seq0, info, tok);
+    // the thread index rebuilt from the wave's scalar index and the lane count (nothing vector survives CHAIN_CUT_VGPRS; a reload
+    // from scratch would cost a memory round trip at the start of every block); opaque to the optimiser, so the per-lane offsets
+    // derived from it are recomputed per block instead of being hoisted out of the block loop and spilled
+    int tid = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(tid));
+    diag_block_factor<false, false, true>(smem, Ab, ld, inv16b, col0, 8, fail, nullptr, pubword, seq0, info, tid + 0x10000);
 }
 
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __restrict__ A, int ld, int nblk,
@@ -234,12 +237,12 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __res
             }
         } else {
             CHAIN_CUT_VGPRS();
-            chain_follow_phase(A, ld, b, info, sig, base);
+            chain_follow_phase(A, ld, b, info, sig, base, wave);
         }
         CHAIN_CUT_VGPRS();
         __syncthreads();
         if (wave == 0) CTRACE(b, 3);
-        chain_factor_phase(Ab, ld, inv16 + (size_t)b * (8 * 256), b * BLK, sig + SIGW_PANEL, base + 8ull * b, info);
+        chain_factor_phase(Ab, ld, inv16 + (size_t)b * (8 * 256), b * BLK, sig + SIGW_PANEL, base + 8ull * b, info, wave);
         CHAIN_CUT_VGPRS();
         if (wave == 15) CTRACE(b, 4);
         __syncthreads();                                         // (F(b + 2) writes the tile area again)
@@ -285,6 +288,31 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
     __syncthreads();
     auto lval = [&](int jb, int m, int s) { return ld_sc1(Lkk + (size_t)(m * 16 + 4 * s + (lane >> 4)) * ld + jb * 16 + (lane & 15)); };
     auto ival = [&](int jb, int s) { return ld_sc1(inv16k + jb * 256 + (4 * s + (lane >> 4)) * 16 + (lane & 15)); };
+    bool dead = false;                                           // a wait gave up: finish without waiting (the update is marked failed)
+    // CRIT: the resident strips do not wait for the chain's panel word before they fetch the inverse of diagonal tile jb — they poll
+    // the DATA: inv16 is filled with an all-ones pattern before the factorisation (factor_enqueue), no computed value has it, and
+    // an 8-byte word is stored whole, so a lane that sees four real values has the final ones.  One round trip instead of two on
+    // the path from the chain's last panel to the next diagonal block; the row tiles of the panel (they overwrite live matrix
+    // entries: no pattern possible) are still taken behind the word.
+    auto ival_poll = [&](int jb, double (&iv)[4]) {
+        for (int it = 0; it < POLL_SPINS; ++it) {
+            bool miss = false;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                iv[s] = ival(jb, s);
+                miss |= __double_as_longlong(iv[s]) == -1ll;
+            }
+            if (!__any(miss)) return;
+            if (dead) return;
+            if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!dead && lane == 0) {
+            st_info(info, INT_MIN);
+            note_giveup(8, k);
+        }
+        dead = true;
+    };
     auto store_tile = [&](int jb, const v4d& t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -293,7 +321,6 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
             else *dst = t[i];
         }
     };
-    bool dead = false;                                           // a wait gave up: finish without waiting (the update is marked failed)
     int seen = *(volatile lds_int_t*)&avail;                     // panels known to be out
     auto await = [&](int jb) {                                   // panel jb of block k is out
         if (dead || seen > jb) return;
@@ -372,14 +399,18 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
         } else {
 #pragma unroll
             for (int jb = 0; jb < TRSM_NA; ++jb) {
-                await(jb);
                 double iv[4], lv[TRSM_NA][4];
+                if (crit) {
+                    ival_poll(jb, iv);
+                } else {
+                    await(jb);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) iv[s] = ival(jb, s);
+                    for (int s = 0; s < 4; ++s) iv[s] = ival(jb, s);
 #pragma unroll
-                for (int j = jb + 1; j < TRSM_NA; ++j)
+                    for (int j = jb + 1; j < TRSM_NA; ++j)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) lv[j][s] = lval(j, jb, s);
+                        for (int s = 0; s < 4; ++s) lv[j][s] = lval(j, jb, s);
+                }
                 v4d nw = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) nw = mfma_f64(iv[s], acc[jb][s], nw);
@@ -388,14 +419,19 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) *(volatile lds_int_t*)&ready = jb + 1;
                 store_tile(jb, nw);
+                if (crit) {
+                    drain_stores();
+                    if (lane == 0) raise_word(prog, pb + jb + 1);
+                    await(jb);                                   // the panel's row tiles
+#pragma unroll
+                    for (int j = jb + 1; j < TRSM_NA; ++j)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) lv[j][s] = lval(j, jb, s);
+                }
 #pragma unroll
                 for (int j = jb + 1; j < TRSM_NA; ++j)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[j] = mfma_f64(-lv[j][s], nw[s], acc[j]);
-                if (crit) {
-                    drain_stores();
-                    if (lane == 0) raise_word(prog, pb + jb + 1);
-                }
             }
         }
         if (crit) {
@@ -478,24 +514,38 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                await(TRSM_NA + j);
                 double iv[4], lo[NB][4];
+                if (crit) {
+                    ival_poll(TRSM_NA + j, iv);
+                } else {
+                    await(TRSM_NA + j);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) iv[s] = ival(TRSM_NA + j, s);
+                    for (int s = 0; s < 4; ++s) iv[s] = ival(TRSM_NA + j, s);
 #pragma unroll
-                for (int j2 = j + 1; j2 < NB; ++j2)
+                    for (int j2 = j + 1; j2 < NB; ++j2)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) lo[j2][s] = lval(TRSM_NA + j2, TRSM_NA + j, s);
+                        for (int s = 0; s < 4; ++s) lo[j2][s] = lval(TRSM_NA + j2, TRSM_NA + j, s);
+                }
                 v4d nw = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) nw = mfma_f64(iv[s], acc[j][s], nw);
                 acc[j] = nw;
                 store_tile(TRSM_NA + j, nw);
+                if (crit) {
+                    publish(TRSM_NA + j + 1);
+                    if (j + 1 < NB) {
+                        await(TRSM_NA + j);                      // the panel's row tiles (the last panel has none)
+#pragma unroll
+                        for (int j2 = j + 1; j2 < NB; ++j2)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) lo[j2][s] = lval(TRSM_NA + j2, TRSM_NA + j, s);
+                    }
+                }
 #pragma unroll
                 for (int j2 = j + 1; j2 < NB; ++j2)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[j2] = mfma_f64(-lo[j2][s], nw[s], acc[j2]);
-                publish(TRSM_NA + j + 1);
+                if (!crit) publish(TRSM_NA + j + 1);
             }
         }
     }

@@ -218,7 +218,9 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
     volatile lds_int_t* xread = (volatile lds_int_t*)(unsigned)(unsigned long long)(Ss + 256);
     // (tidtok: an opaque zero the persistent chain kernel passes so that the per-lane offsets below are recomputed per block instead
     // of being hoisted out of its block loop, where they would stay live — and spill — through the follower phase)
-    const int tid = threadIdx.x + tidtok, lane = tid & 63;
+    // tidtok >= 0x10000: the caller passes the thread index itself (+ 0x10000), rebuilt from scalar state — the chain kernel cuts
+    // every vector live range between its phases and would otherwise fetch the index from scratch at the start of each block
+    const int tid = tidtok >= 0x10000 ? tidtok - 0x10000 : (int)threadIdx.x + tidtok, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: tile decode runs on the SALU
     const int r16 = lane & 15, q = lane >> 4;
     constexpr int NW = DIAG_THREADS / 64;
