@@ -2,9 +2,12 @@
 # Collect the round's rocprofv3 evidence for bench.py (run on the GPU box from the repo root):
 #   1. kernel trace + stats of the default bench command           -> profiles/<tag>_bench_kernel_stats.csv
 #   2. separate --pmc passes for FETCH_SIZE and WRITE_SIZE           -> profiles/<tag>_pmc_summary.json (carries the source hash)
-# usage: bash tools/collect_profiles.sh r02_v3
+#   3. the bench line itself (no profiler)                           -> profiles/<tag>_bench.json
+#   4. device timeline of one N=4096 update under the resident chain -> profiles/<tag>_chain_timeline.log (needs tools/libbosship_t3.so:
+#      python tools/chain_trace3.py --build on the CPU box first)
+# usage: bash tools/collect_profiles.sh r03_v1
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 mkdir -p $out profiles
 export TMPDIR=/tmp
@@ -13,6 +16,8 @@ cp $(find $out/stats -name "s_kernel_stats.csv" | head -1) profiles/${tag}_bench
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -o f -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $out/bench_f.json 2> $out/f.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -o w -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $out/bench_w.json 2> $out/w.err
 python3 tools/pmc_summary.py $(find $out/pmc_f -name "f_counter_collection.csv" | head -1) $(find $out/pmc_w -name "w_counter_collection.csv" | head -1) profiles/${tag}_pmc_summary.json
-cp profiles/${tag}_pmc_summary.json gpurun_out/
-cp profiles/${tag}_bench_kernel_stats.csv gpurun_out/
+python3 bench.py --steps 50 --warmup 5 > profiles/${tag}_bench.json 2> $out/bench.err
+if [ -f tools/libbosship_t3.so ]; then python3 tools/chain_trace3.py 4096 > profiles/${tag}_chain_timeline.log 2> $out/trace.err || true; fi
+cp profiles/${tag}_pmc_summary.json profiles/${tag}_bench_kernel_stats.csv profiles/${tag}_bench.json gpurun_out/
+[ -f profiles/${tag}_chain_timeline.log ] && cp profiles/${tag}_chain_timeline.log gpurun_out/
 echo "profiles written for $tag"
