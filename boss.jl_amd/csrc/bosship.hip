@@ -210,6 +210,7 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)few_back_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)few_w_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize, PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)few_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)linvt_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -344,6 +345,10 @@ struct boss_gp {
     double *lamX = nullptr, *ampX = nullptr, *noiseX = nullptr;
     // explicit L⁻ᵀ for calls with one to four candidates (built on the second such call on a factorisation)
     double *Winv = nullptr, *Linv = nullptr;   // L⁻ᵀ (upper) and L⁻¹ (lower)
+    // W_i = Dinv2_i · L[i, i-1] (few_w_kernel): built by the first few-candidates call on a factorisation
+    double* W2 = nullptr;
+    int w2_np = 0;
+    unsigned long long w2_gen = ~0ull;
     bool have_winv = false;
     int few_calls = 0;
     int append_calls = 0;                      // single-observation appends since the last update (the second one builds the inverses)

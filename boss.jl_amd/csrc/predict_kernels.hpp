@@ -288,17 +288,17 @@ __global__ __launch_bounds__(256) void kstar_rows_kernel(const double* __restric
 }
 
 // GU = GemmDirect<4,1,2,2,D>: 128 rows × 32 candidates per workgroup, K = 256
+// yblk: the 128-row block below row block ib that this workgroup updates (0 = the first one)
 template <class GU>
-__global__ __launch_bounds__(GU::NTHREADS) void few_update_kernel(const double* __restrict__ A, int ld, int Np, int ib,
-                                                                  const double* __restrict__ V, double* __restrict__ R) {
+__device__ __forceinline__ void few_update_body(const double* __restrict__ A, int ld, int Np, int ib,
+                                                const double* __restrict__ V, double* __restrict__ R, int yblk, int tile) {
     static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
     constexpr int TM = GU::TM, TN = GU::TN;
-    V += (size_t)blockIdx.x * Np * 32;                       // candidate tile (fastest in dispatch order: the tiles of one
-                                                             // row block share its panel of L in L2)
-    R += (size_t)blockIdx.x * Np * 32;
+    V += (size_t)tile * Np * 32;
+    R += (size_t)tile * Np * 32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r0 = (ib + 1) * PRED_RB + blockIdx.y * BLK;    // first row of this workgroup's block
+    const int r0 = (ib + 1) * PRED_RB + yblk * BLK;          // first row of this workgroup's block
     double* Rb = R + (size_t)r0 * 32;
     v4d acc[TM][TN];
 #pragma unroll
@@ -317,6 +317,176 @@ __global__ __launch_bounds__(GU::NTHREADS) void few_update_kernel(const double* 
         for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int i = 0; i < 4; ++i) Rb[row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
+    }
+}
+
+template <class GU>
+__global__ __launch_bounds__(GU::NTHREADS) void few_update_kernel(const double* __restrict__ A, int ld, int Np, int ib,
+                                                                  const double* __restrict__ V, double* __restrict__ R) {
+    few_update_body<GU>(A, ld, Np, ib, V, R, blockIdx.y, blockIdx.x);   // (tiles fastest in dispatch order)
+}
+
+// ------------------------------------------------------------------------------------------
+// The same substitution with ONE launch per 256-row step and no dependent pair of GEMMs inside a step.  With
+//     W_i = Dinv2_i · L[i, i-1]                        (few_w_kernel, once per factorisation)
+// the step reads
+//     V_i = Dinv2_i · R_i' − W_i · V_{i-1}             R_i' = K*_i − Σ_{j<=i-2} L[i, j] V_j
+// so step i needs V_{i-1} and the updates of the steps up to i-2 only, and the update that V_{i-1} owes the blocks below
+// block i can run BESIDE it in the same launch (nothing in a launch depends on anything else in it):
+//     few_step_kernel(i):   the first 8·tiles workgroups: rows 32p .. 32p+31 of V_i of one tile, a K = 32 (p + 1) + 256 product
+//                                             split four ways along K over the workgroup's waves (<= 128 MFMAs per wave) and
+//                                             summed through LDS
+//                           the others:       R_j −= L[j, i-1] V_{i-1} for the 128-row blocks below block i (few_update_body).
+//                                             Workgroup n runs on XCD n mod 8: the 128-row blocks are dealt to the XCDs (block
+//                                             8k + x on XCD x, every tile of it), so each slice of the L panel is pulled into
+//                                             ONE L2 — with the tiles fastest in dispatch order every XCD read the whole panel.
+// The launch-per-GEMM form above spent 16.5 µs of every step in a finish kernel with one workgroup per tile (13.6 µs of
+// MFMA issue on one CU) before the update could start: 0.77 ms for M = 1024 at N = 4096 against ... here.
+// Per-step partial sums of Σv², v·z go to part[tile][step][y][64] and are added in a fixed order by few_sum_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int FEW_STEP_PARTS = 8;
+
+// W_b (b = blockIdx.y + 1) columns 32·blockIdx.x .. +31, column-major 256×256 like Dinv2
+template <class G>
+__global__ __launch_bounds__(G::NTHREADS) void few_w_kernel(const double* __restrict__ A, int ld,
+                                                            const double* __restrict__ Dinv2, double* __restrict__ W2) {
+    constexpr int RB = G::BM, TM = G::TM, TN = G::TN, LDR = PredictLds<G>::LDR;
+    static_assert(RB == PRED_RB && TN == 2 && TM % 2 == 0, "256-row blocks, 32 columns per workgroup");
+    extern __shared__ double lds[];
+    double* Rs = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y + 1, c0 = blockIdx.x * 32;
+    const double* Lb = A + (size_t)b * RB + (size_t)((b - 1) * RB + c0) * ld;
+#pragma unroll 8
+    for (int q = 0; q < RB * 32 / 256; ++q) {                // column q of the slice, one row per thread
+        Rs[tid * LDR + q] = Lb[tid + (size_t)q * ld];
+    }
+    __syncthreads();
+    v4d acc2[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    G::run_Blds_tri(Dinv2 + (size_t)b * RB * RB, RB, Rs, LDR, acc2);
+    double* Wb = W2 + (size_t)b * RB * RB;
+#pragma unroll
+    for (int m = 0; m < TM; m += 2) {
+        const int row = G::tri_row_of(wave, m, lane);        // even row; tile m + 1 holds the odd one below it
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<v2d*>(Wb + row + (size_t)(c0 + G::col_of(0, n, i, lane)) * RB) = v2d{acc2[m][n][i], acc2[m + 1][n][i]};
+    }
+}
+
+template <class GU>
+__global__ __launch_bounds__(256) void few_step_kernel(const double* __restrict__ A, int ld, int Np, int nb, int ib, int Np_tiles,
+                                                       double* __restrict__ R, const double* __restrict__ Dinv2,
+                                                       const double* __restrict__ W2, double* __restrict__ V,
+                                                       double* __restrict__ part) {
+    static_assert(GU::NTHREADS == 256, "both halves of the launch use 4 waves");
+    const int ftiles = Np_tiles;
+    if ((int)blockIdx.x >= FEW_STEP_PARTS * ftiles) {
+        const int n = (int)blockIdx.x - FEW_STEP_PARTS * ftiles;            // (8·tiles is a multiple of 8: n mod 8 is the XCD)
+        const int k = n >> 3, blk = 8 * (k / ftiles) + (n & 7);
+        if (blk >= (nb - 1 - ib) * (PRED_RB / BLK)) return;                 // (the grid is padded to whole groups of 8 blocks)
+        few_update_body<GU>(A, ld, Np, ib - 1, V, R, 2 + blk, k % ftiles);
+        return;
+    }
+    typedef GemmDirect<1, 1, 2, 2, 8> G1;                    // 32 rows × 32 candidates per wave; its row offset is wave·32: undone below
+    __shared__ double red[3][32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = (int)blockIdx.x / ftiles, tile = (int)blockIdx.x % ftiles;
+    R += (size_t)tile * Np * 32;
+    V += (size_t)tile * Np * 32;
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+    {   // Dinv2_ib[rows, 0 : 32 (p + 1)) · R_ib: this wave's quarter of the columns
+        const int kn = 8 * (p + 1), k0 = wave * kn;
+        G1::template run<1>(Dinv2 + (size_t)ib * PRED_RB * PRED_RB + 32 * p - 32 * wave + (size_t)k0 * PRED_RB, PRED_RB,
+                            R + ((size_t)ib * PRED_RB + k0) * 32, 32, kn, acc);
+    }
+    if (ib > 0) {                                            // − W_ib[rows, :] · V_{ib-1}
+        const int k0 = 64 * wave;
+        G1::template run<-1>(W2 + (size_t)ib * PRED_RB * PRED_RB + 32 * p - 32 * wave + (size_t)k0 * PRED_RB, PRED_RB,
+                             V + ((size_t)(ib - 1) * PRED_RB + k0) * 32, 32, 64, acc);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<v2d*>(&red[wave - 1][G1::row_of(0, m, lane) * 32 + G1::col_of(0, 0, i, lane)]) = v2d{acc[m][0][i], acc[m][1][i]};
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    double ps[2][4], pz[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ps[n][i] = pz[n][i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int rl = G1::row_of(0, m, lane);
+        const int row = ib * PRED_RB + 32 * p + rl;
+        const double zr = A[(size_t)row * ld + Np];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = G1::col_of(0, 0, i, lane);
+            v2d v = v2d{acc[m][0][i], acc[m][1][i]};
+#pragma unroll
+            for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const v2d*>(&red[w][rl * 32 + col]);
+            *reinterpret_cast<v2d*>(V + (size_t)row * 32 + col) = v;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                ps[n][i] = __builtin_fma(v[n], v[n], ps[n][i]);
+                pz[n][i] = __builtin_fma(v[n], zr, pz[n][i]);
+            }
+        }
+    }
+    double* pt = part + (((size_t)tile * nb + ib) * FEW_STEP_PARTS + p) * 64;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double sv = ps[n][i], z = pz[n][i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                sv += __shfl_xor(sv, off);
+                z += __shfl_xor(z, off);
+            }
+            if ((lane & 15) == 0) {
+                const int col = G1::col_of(0, n, i, lane);
+                pt[col] = sv;
+                pt[32 + col] = z;
+            }
+        }
+}
+
+// μ, σ² from the per-step partial sums: four quarters of the (step, part) list side by side, each in order, then the quarters in order
+__global__ __launch_bounds__(256) void few_sum_kernel(const double* __restrict__ part, int nb, const double* __restrict__ mean_s,
+                                                      int M, double amp2, double* __restrict__ mu_out,
+                                                      double* __restrict__ var_out, int aug) {
+    __shared__ double q[4][64];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 32, v = tid & 63, g = tid >> 6;
+    const int nk = nb * FEW_STEP_PARTS, k0 = g * (nk / 4), k1 = g == 3 ? nk : k0 + nk / 4;
+    const double* pt = part + (size_t)blockIdx.x * nk * 64 + v;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) s += pt[(size_t)k * 64];
+    q[g][v] = s;
+    __syncthreads();
+    if (tid < 32 && c0 + tid < M) {
+        const double ss = ((q[0][tid] + q[1][tid]) + q[2][tid]) + q[3][tid];
+        const double z = ((q[0][32 + tid] + q[1][32 + tid]) + q[2][32 + tid]) + q[3][32 + tid];
+        mu_out[c0 + tid] = (mean_s ? mean_s[c0 + tid] : 0.0) + z;
+        var_out[c0 + tid] = aug == 2 ? -ss : aug ? fmax(0.0, amp2 - ss) : amp2 - ss + PREDICT_JITTER;
     }
 }
 
