@@ -349,6 +349,7 @@ struct boss_gp {
     double* W2 = nullptr;
     int w2_np = 0;
     unsigned long long w2_gen = ~0ull;
+    bool w2_used = false;                      // (since the last factorisation: the next one builds W beside the block inverses)
     bool have_winv = false;
     int few_calls = 0;
     int append_calls = 0;                      // single-observation appends since the last update (the second one builds the inverses)

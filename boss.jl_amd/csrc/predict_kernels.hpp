@@ -288,65 +288,69 @@ __global__ __launch_bounds__(256) void kstar_rows_kernel(const double* __restric
 }
 
 // GU = GemmDirect<4,1,2,2,D>: 128 rows × 32 candidates per workgroup, K = 256
-// yblk: the 128-row block below row block ib that this workgroup updates (0 = the first one)
+// R[r0 : r0 + BM, tile] −= L[r0 : r0 + BM, 256·isrc : 256·isrc + K] · V[256·isrc : 256·isrc + K, tile]
 template <class GU>
-__device__ __forceinline__ void few_update_body(const double* __restrict__ A, int ld, int Np, int ib,
-                                                const double* __restrict__ V, double* __restrict__ R, int yblk, int tile) {
-    static_assert(GU::WC == 1 && GU::BM == BLK && GU::BN == 32, "128×32 tiles");
-    constexpr int TM = GU::TM, TN = GU::TN;
+__device__ __forceinline__ void few_update_body(const double* __restrict__ A, int ld, int Np, int isrc, int K, int r0,
+                                                const double* __restrict__ V, double* __restrict__ R, int tile) {
+    static_assert(GU::WC == 1 && GU::BN == 32 && GU::TN == 2, "BM×32 tiles");
+    constexpr int TM = GU::TM;
     V += (size_t)tile * Np * 32;
     R += (size_t)tile * Np * 32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r0 = (ib + 1) * PRED_RB + yblk * BLK;          // first row of this workgroup's block
+    if (wave >= GU::NWAVES) return;                          // (launched with more waves than the tile uses: few_step_kernel)
     double* Rb = R + (size_t)r0 * 32;
-    v4d acc[TM][TN];
+    v4d acc[TM][2];
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
         const int row = GU::row_of(wave, m, lane);
 #pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[m][n][i] = Rb[row * 32 + GU::col_of(0, n, i, lane)];
+        for (int i = 0; i < 4; ++i) {                        // columns 2c, 2c+1 = tiles n = 0, 1
+            const v2d v = *reinterpret_cast<const v2d*>(Rb + row * 32 + GU::col_of(0, 0, i, lane));
+            acc[m][0][i] = v[0];
+            acc[m][1][i] = v[1];
+        }
     }
-    GU::template run<-1>(A + (size_t)r0 + (size_t)ib * PRED_RB * ld, ld, V + (size_t)ib * PRED_RB * 32, 32, PRED_RB, acc);
+    GU::template run<-1>(A + (size_t)r0 + (size_t)isrc * PRED_RB * ld, ld, V + (size_t)isrc * PRED_RB * 32, 32, K, acc);
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
         const int row = GU::row_of(wave, m, lane);
 #pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) Rb[row * 32 + GU::col_of(0, n, i, lane)] = acc[m][n][i];
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<v2d*>(Rb + row * 32 + GU::col_of(0, 0, i, lane)) = v2d{acc[m][0][i], acc[m][1][i]};
     }
 }
 
 template <class GU>
 __global__ __launch_bounds__(GU::NTHREADS) void few_update_kernel(const double* __restrict__ A, int ld, int Np, int ib,
                                                                   const double* __restrict__ V, double* __restrict__ R) {
-    few_update_body<GU>(A, ld, Np, ib, V, R, blockIdx.y, blockIdx.x);   // (tiles fastest in dispatch order)
+    few_update_body<GU>(A, ld, Np, ib, PRED_RB, (ib + 1) * PRED_RB + (int)blockIdx.y * GU::BM, V, R, blockIdx.x);   // (tiles fastest in dispatch order)
 }
 
 // ------------------------------------------------------------------------------------------
 // The same substitution with ONE launch per 256-row step and no dependent pair of GEMMs inside a step.  With
-//     W_i = Dinv2_i · L[i, i-1]                        (few_w_kernel, once per factorisation)
-// the step reads
-//     V_i = Dinv2_i · R_i' − W_i · V_{i-1}             R_i' = K*_i − Σ_{j<=i-2} L[i, j] V_j
-// so step i needs V_{i-1} and the updates of the steps up to i-2 only, and the update that V_{i-1} owes the blocks below
-// block i can run BESIDE it in the same launch (nothing in a launch depends on anything else in it):
-//     few_step_kernel(i):   the first 8·tiles workgroups: rows 32p .. 32p+31 of V_i of one tile, a K = 32 (p + 1) + 256 product
-//                                             split four ways along K over the workgroup's waves (<= 128 MFMAs per wave) and
-//                                             summed through LDS
-//                           the others:       R_j −= L[j, i-1] V_{i-1} for the 128-row blocks below block i (few_update_body).
-//                                             Workgroup n runs on XCD n mod 8: the 128-row blocks are dealt to the XCDs (block
-//                                             8k + x on XCD x, every tile of it), so each slice of the L panel is pulled into
-//                                             ONE L2 — with the tiles fastest in dispatch order every XCD read the whole panel.
-// The launch-per-GEMM form above spent 16.5 µs of every step in a finish kernel with one workgroup per tile (13.6 µs of
-// MFMA issue on one CU) before the update could start: 0.77 ms for M = 1024 at N = 4096 against ... here.
-// Per-step partial sums of Σv², v·z go to part[tile][step][y][64] and are added in a fixed order by few_sum_kernel.
+//     W_i = Dinv2_i · L[i, i-1]   and, for even i,   W'_i = Dinv2_i · L[i, i-2]          (few_w_kernel, once per factorisation)
+// a step reads
+//     odd i :   V_i = Dinv2_i · R_i' − W_i V_{i-1}                         R_i' = K*_i − Σ_{j<=i-2} L[i, j] V_j
+//     even i:   V_i = Dinv2_i · R_i' − W'_i V_{i-2} − W_i V_{i-1}          R_i' = K*_i − Σ_{j<=i-3} L[i, j] V_j
+// so the residual blocks only have to receive the V's in PAIRS: the launch of an even step i >= 2 also carries the update
+// R_j −= L[j, i-2 : i] [V_{i-2}; V_{i-1}] (K = 512) of every block j > i, which needs nothing the same launch computes, and an
+// odd step is its 8·tiles step workgroups alone.
+//     few_step_kernel(i):   the first 8·tiles workgroups: rows 32p .. 32p+31 of V_i of one tile, a K = 32 (p + 1) + 256 (or 512)
+//                                             product split four ways along K over the workgroup's waves (<= 192 MFMAs per
+//                                             wave) and summed through LDS
+//                           the others:       the pair update, few_update_body on GU::BM-row blocks.  Workgroup n runs on XCD
+//                                             n mod 8: whole groups of 8 blocks are dealt block 8k + x -> XCD x (every tile of
+//                                             it: each slice of the L panel is pulled into ONE L2), what is left tile by tile.
+// The launch-per-GEMM form above spends 16.5 µs of every step in a finish kernel with one workgroup per tile (13.6 µs of MFMA
+// issue on one CU) before the update can start, and every launch of the update ≈10 µs in ramp, operand latency and tail.
+// Per-step partial sums of Σv², v·z go to part[tile][step][p][64] and are added in a fixed order by few_sum_kernel.
+// W lives in slabs of 256 × 512 per block (column-major, ld 256): columns 256.. = W_i, columns 0..255 = W'_i (even i >= 2).
 // ------------------------------------------------------------------------------------------
 constexpr int FEW_STEP_PARTS = 8;
+constexpr size_t FEW_W_SLAB = (size_t)PRED_RB * 2 * PRED_RB;
 
-// W_b (b = blockIdx.y + 1) columns 32·blockIdx.x .. +31, column-major 256×256 like Dinv2
+// blockIdx.y = 2 b + which (which = 1: W_b, 0: W'_b), columns 32·blockIdx.x .. +31 of it
 template <class G>
 __global__ __launch_bounds__(G::NTHREADS) void few_w_kernel(const double* __restrict__ A, int ld,
                                                             const double* __restrict__ Dinv2, double* __restrict__ W2) {
@@ -356,8 +360,9 @@ __global__ __launch_bounds__(G::NTHREADS) void few_w_kernel(const double* __rest
     double* Rs = lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y + 1, c0 = blockIdx.x * 32;
-    const double* Lb = A + (size_t)b * RB + (size_t)((b - 1) * RB + c0) * ld;
+    const int b = blockIdx.y >> 1, which = blockIdx.y & 1, c0 = blockIdx.x * 32;
+    if (which ? b < 1 : (b < 2 || (b & 1))) return;
+    const double* Lb = A + (size_t)b * RB + (size_t)((b - 2 + which) * RB + c0) * ld;
 #pragma unroll 8
     for (int q = 0; q < RB * 32 / 256; ++q) {                // column q of the slice, one row per thread
         Rs[tid * LDR + q] = Lb[tid + (size_t)q * ld];
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(G::NTHREADS) void few_w_kernel(const double* __rest
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc2[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
     G::run_Blds_tri(Dinv2 + (size_t)b * RB * RB, RB, Rs, LDR, acc2);
-    double* Wb = W2 + (size_t)b * RB * RB;
+    double* Wb = W2 + (size_t)b * FEW_W_SLAB + (size_t)which * RB * RB;
 #pragma unroll
     for (int m = 0; m < TM; m += 2) {
         const int row = G::tri_row_of(wave, m, lane);        // even row; tile m + 1 holds the odd one below it
@@ -386,13 +391,24 @@ __global__ __launch_bounds__(256) void few_step_kernel(const double* __restrict_
                                                        double* __restrict__ R, const double* __restrict__ Dinv2,
                                                        const double* __restrict__ W2, double* __restrict__ V,
                                                        double* __restrict__ part) {
-    static_assert(GU::NTHREADS == 256, "both halves of the launch use 4 waves");
+    static_assert(GU::NTHREADS <= 256, "the step part uses 4 waves");
     const int ftiles = Np_tiles;
-    if ((int)blockIdx.x >= FEW_STEP_PARTS * ftiles) {
+    if ((int)blockIdx.x >= FEW_STEP_PARTS * ftiles) {        // (even steps from 2 on)
+        constexpr int PER = PRED_RB / GU::BM;
         const int n = (int)blockIdx.x - FEW_STEP_PARTS * ftiles;            // (8·tiles is a multiple of 8: n mod 8 is the XCD)
-        const int k = n >> 3, blk = 8 * (k / ftiles) + (n & 7);
-        if (blk >= (nb - 1 - ib) * (PRED_RB / BLK)) return;                 // (the grid is padded to whole groups of 8 blocks)
-        few_update_body<GU>(A, ld, Np, ib - 1, V, R, 2 + blk, k % ftiles);
+        const int nblk = (nb - 1 - ib) * PER, full = (nblk >> 3) * ftiles;
+        const int k = n >> 3, x = n & 7;
+        int blk, tile;
+        if (k < full) {
+            blk = 8 * (k / ftiles) + x;
+            tile = k % ftiles;
+        } else {
+            const int m = (k - full) * 8 + x;
+            if (m >= (nblk & 7) * ftiles) return;
+            blk = (nblk & ~7) + m / ftiles;
+            tile = m % ftiles;
+        }
+        few_update_body<GU>(A, ld, Np, ib - 2, 2 * PRED_RB, (ib + 1) * PRED_RB + blk * GU::BM, V, R, tile);
         return;
     }
     typedef GemmDirect<1, 1, 2, 2, 8> G1;                    // 32 rows × 32 candidates per wave; its row offset is wave·32: undone below
@@ -412,10 +428,11 @@ __global__ __launch_bounds__(256) void few_step_kernel(const double* __restrict_
         G1::template run<1>(Dinv2 + (size_t)ib * PRED_RB * PRED_RB + 32 * p - 32 * wave + (size_t)k0 * PRED_RB, PRED_RB,
                             R + ((size_t)ib * PRED_RB + k0) * 32, 32, kn, acc);
     }
-    if (ib > 0) {                                            // − W_ib[rows, :] · V_{ib-1}
-        const int k0 = 64 * wave;
-        G1::template run<-1>(W2 + (size_t)ib * PRED_RB * PRED_RB + 32 * p - 32 * wave + (size_t)k0 * PRED_RB, PRED_RB,
-                             V + ((size_t)(ib - 1) * PRED_RB + k0) * 32, 32, 64, acc);
+    if (ib > 0) {                                            // − W_ib[rows, :] · V_{ib-1}, for an even step − [W'_ib | W_ib][rows, :] · [V_{ib-2}; V_{ib-1}]
+        const int two = (ib & 1) == 0 ? 1 : 0;
+        const int kn = two ? 128 : 64, k0 = kn * wave, c0 = two ? 0 : PRED_RB;
+        G1::template run<-1>(W2 + (size_t)ib * FEW_W_SLAB + 32 * p - 32 * wave + (size_t)(c0 + k0) * PRED_RB, PRED_RB,
+                             V + ((size_t)(ib - 1 - two) * PRED_RB + k0) * 32, 32, kn, acc);
     }
     if (wave > 0) {
 #pragma unroll
