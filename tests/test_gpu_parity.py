@@ -1252,6 +1252,55 @@ def test_few_candidates_path(api, O, N, M):
     g.close()
 
 
+@pytest.mark.parametrize("N,M", [(1024, 40), (1536, 300), (2300, 1000), (4096, 1024), (5000, 70)])
+def test_first_call_on_a_factorisation_steps_with_pair_updates(api, O, N, M):
+    """The first prediction on a factorisation with 33 .. 4096 candidates: one launch per 256-row step (V_i from the block
+    inverse and the precomputed W_i, W'_i), the residual blocks updated in pairs on the even steps.  Odd and even block counts,
+    ragged last tiles, an update in between (W must follow the new factor), against the oracle."""
+    rng = np.random.default_rng(3 * N + M)
+    d = 5
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0) / 2 + 0.05 * rng.standard_normal(N)
+    mean = 0.2 - 0.1 * X[1]
+    Xs = rng.uniform(0, 1, (d, M))
+    ms = 0.2 - 0.1 * Xs[1]
+    g = api.GP(X, y, "matern52")
+    for lam0, noise in ((0.45, 0.05), (0.6, 0.08)):
+        lam = np.full(d, lam0)
+        g.update(lam, 1.2, noise, mean)
+        post = O.gp_fit(X, y, "matern52", lam, 1.2, noise, mean=mean)
+        mu, var = g.predict(Xs, ms)                          # first call on this factorisation
+        mu_o, var_o = O.gp_mean_and_var(post, Xs, ms)
+        assert np.allclose(mu, mu_o, rtol=0, atol=1e-9) and np.allclose(var, var_o, rtol=0, atol=1e-9)
+    g.close()
+
+
+def test_first_call_steps_agree_with_the_two_launch_fallback():
+    """BOSS_NO_FEW_W=1 keeps the round-2 form of the few-candidates steps (finish kernel, then update kernel: what the library
+    falls back to when it cannot allocate W): same moments as the one-launch-per-step form up to summation order."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from boss_jl_amd import api
+rng = np.random.default_rng(5)
+d, N, M = 6, 3000, 700
+X = rng.uniform(0, 1, (d, N)); y = np.sin(2*np.pi*X).sum(0) + 0.05*rng.standard_normal(N)
+Xs = rng.uniform(0, 1, (d, M)); lam = np.full(d, 0.5)
+g = api.GP(X, y, "matern52")
+g.update(lam, 1.0, 0.05)
+mu, var = g.predict(Xs)
+print("RES", " ".join(repr(float(v)) for v in np.concatenate([mu[:50], var[:50], [mu.sum(), var.sum()]])))
+''' % ROOT
+    out = {}
+    for tag, extra in (("steps", {}), ("fallback", {"BOSS_NO_FEW_W": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "RES" in r.stdout, tag + ": " + r.stdout + r.stderr
+        out[tag] = np.array([float(v) for v in r.stdout.split("RES")[1].split()])
+    assert np.allclose(out["steps"], out["fallback"], rtol=0, atol=1e-10 * (1 + np.abs(out["fallback"]).max()))
+
+
 @pytest.mark.parametrize("N,M", [(1024, 1), (1300, 3), (2048, 4), (4096, 1), (1024, 20), (1300, 33), (2048, 200), (6000, 1), (6000, 2)])
 def test_repeated_few_candidate_calls_use_the_explicit_inverse(api, O, N, M):
     """One to four candidates per call, many calls per posterior (the reference's `acq.(eachcol(xs))` pattern): from
