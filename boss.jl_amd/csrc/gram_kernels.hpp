@@ -31,12 +31,20 @@ struct HypArgs {
 // cleared failed-pivot flag: the update's preparation is one kernel.
 __global__ void scale_points_args_kernel(HypArgs par, const double* __restrict__ Xraw, double* __restrict__ Xsc,
                                          double* __restrict__ par_dev, int ldp, double* __restrict__ A, int ld, int N,
-                                         const double* __restrict__ y, const double* __restrict__ mean, int* __restrict__ info) {
+                                         const double* __restrict__ y, const double* __restrict__ mean, int* __restrict__ info,
+                                         double* __restrict__ inv16_fill) {
+    // inv16_fill (or null): the 16·Np doubles of the diagonal tiles' inverses, set to the all-ones pattern the resident strips
+    // recognise as "not written yet" (chain.hpp) — instead of a memset launch in front of this kernel
     if (blockIdx.x == 0 && threadIdx.x < par.d + 2)
         par_dev[threadIdx.x] = threadIdx.x < par.d ? par.invlam[threadIdx.x] : par.hyp[threadIdx.x - par.d];
     if (blockIdx.x == 0 && threadIdx.x == 0) info[0] = 0;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ldp) return;
+    if (inv16_fill) {
+        const v2d ones = v2d{__longlong_as_double(-1LL), __longlong_as_double(-1LL)};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<v2d*>(inv16_fill + (size_t)(2 * r) * ldp + 2 * (size_t)j) = ones;   // 8 passes × 2·Np doubles = all 16·Np, 16 B per thread per pass
+    }
     for (int k = 0; k < par.d; ++k) Xsc[(size_t)k * ldp + j] = Xraw[(size_t)k * ldp + j] * par.invlam[k];
     double* col = A + (size_t)j * ld + ldp;                   // ldp = Np: the δ^T row block starts at row Np
     col[0] = (j < N) ? (y[j] - mean[j]) : 0.0;
