@@ -1387,6 +1387,34 @@ def test_repeated_single_candidate_calls_on_gradient_and_nonstationary_posterior
     gn.close()
 
 
+def test_first_call_steps_on_gradient_and_nonstationary_posteriors(api, O):
+    """The one-launch-per-step form of the few-candidates substitution with the right-hand sides the other two model families
+    write (aug_kstar_kernel, gibbs_kstar kernels): a few hundred candidates, enough row blocks for the pair updates."""
+    d, n, M = 3, 420, 150                                    # 1680 augmented rows
+    X, y, dY = make_grad(d, n)
+    lam = np.full(d, 0.45)
+    rng = np.random.default_rng(8)
+    Xs = rng.uniform(0, 1, (d, M))
+    gg = api.GradGP(X, y, dY, "matern52")
+    gg.update(lam, 1.2, 0.05, 0.1)
+    pg = O.gradient_gp_fit(X, y, dY, "matern52", lam, 1.2, 0.05, 0.1)
+    mu, var = gg.predict(Xs)
+    mu_o, var_o = O.gradient_gp_mean_and_var(pg, Xs)
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-8) and np.allclose(var, var_o, rtol=0, atol=1e-8)
+    gg.close()
+    N, M = 1500, 300
+    Xn, yn, Xc = make(d, N, M, seed=10)
+    f_lam, f_amp, f_noise = latent(d)
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                   # noqa: E731
+    gn = api.GibbsGP(Xn, yn)
+    gn.update(ev(f_lam, Xn).T, ev(f_amp, Xn), ev(f_noise, Xn))
+    pn = O.nonstationary_fit(Xn, yn, ev(f_lam, Xn).T, ev(f_amp, Xn), ev(f_noise, Xn))
+    mu, var = gn.predict(Xc, ev(f_lam, Xc).T, ev(f_amp, Xc))
+    mu_o, var_o = O.nonstationary_mean_and_var(pn, Xc, ev(f_lam, Xc).T, ev(f_amp, Xc))
+    assert np.allclose(mu, mu_o, rtol=0, atol=1e-8) and np.allclose(var, var_o, rtol=0, atol=1e-8)
+    gn.close()
+
+
 def test_caller_stream(api, O):
     """boss_set_stream: run the library on torch's current (non-default) stream; torch events then see the work."""
     import torch
