@@ -272,6 +272,10 @@ def launch_children(args):
             raise SystemExit(f"--gpus {args.gpus}: only {n_vis} GPU(s) visible and at most {MAX_PROCS_PER_GPU} processes may share one")
         env["BOSS_BENCH_BACKEND"] = "gloo"
         env["BOSS_BENCH_REHEARSAL"] = "1"
+        # several processes on one GPU take turns on its hardware queues: a resident kernel that waits for a kernel of a queue that
+        # is not scheduled right now runs into its (1 s) time-out and the update falls back — correct, but it makes the rehearsal
+        # crawl.  The rehearsal is about the exchange path, not the schedule: event-ordered kernels from the start.
+        env.setdefault("BOSS_NO_CHAIN", "1")
     import __graft_entry__ as entry
     entry.compile_library()                                # once, here (hipcc only: nothing is loaded, no GPU call)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus))
