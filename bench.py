@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 N_OBS, D, M_CAND = 4096, 8, 8192
 FP64_MFMA_PEAK_TFLOPS = 78.6          # AMD MI355X datasheet (vector = matrix fp64); tools/mfma_probe measures 77.6
+ONE_WAVE_ISSUE_TFLOPS = 68.3          # measured: bare fp64 MFMA stream, one wave per SIMD, 256 CUs (profiles/r03_mfma_rate_probe.log)
 KERNEL = "matern52"
 MAX_PROCS_PER_GPU = 6                 # the GPU box's process guard
 
@@ -182,27 +183,34 @@ def cpu_baseline(X, y, Xs, lam):
 
 
 def visible_gpus():
-    """Number of GPUs this process may use, without initialising HIP: the visibility variables, else the KFD topology."""
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            return len([t for t in v.split(",") if t.strip() != ""])
+    """Number of GPUs this process may use, without initialising HIP.  The KFD topology lists every GPU of the HOST; only those
+    whose render node (drm_render_minor -> /dev/dri/renderD<minor>) this process can open count (a container's device cgroup or
+    its /dev/dri mounts hide the others).  The visibility variables can only narrow that down: each is an index list into what
+    the layer below it shows, so the minimum over the ones that are set is an upper bound.  A rank whose LOCAL_RANK still turns
+    out to be beyond the runtime's device count falls back to sharing device 0 (main(): `rehearsal`)."""
     n = 0
     base = "/sys/class/kfd/kfd/topology/nodes"
     try:
         for node in os.listdir(base):
             try:
-                props = open(os.path.join(base, node, "properties")).read()
+                props = dict(l.split()[:2] for l in open(os.path.join(base, node, "properties")).read().splitlines() if len(l.split()) >= 2)
             except OSError:
                 continue
-            for line in props.splitlines():
-                if line.startswith("simd_count") and int(line.split()[1]) > 0:
-                    n += 1
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                       # a CPU node
+            minor = props.get("drm_render_minor")
+            dev = f"/dev/dri/renderD{minor}" if minor not in (None, "0", "-1") else None
+            if dev is None or os.access(dev, os.R_OK | os.W_OK):
+                n += 1
     except OSError:
         pass
-    if n == 0:                                             # last resort (counts devices through the runtime)
+    if n == 0:                                             # last resort (counts devices through the runtime; no context is created)
         import torch
         n = torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
     return n
 
 
@@ -272,10 +280,9 @@ def launch_children(args):
             raise SystemExit(f"--gpus {args.gpus}: only {n_vis} GPU(s) visible and at most {MAX_PROCS_PER_GPU} processes may share one")
         env["BOSS_BENCH_BACKEND"] = "gloo"
         env["BOSS_BENCH_REHEARSAL"] = "1"
-        # several processes on one GPU take turns on its hardware queues: a resident kernel that waits for a kernel of a queue that
-        # is not scheduled right now runs into its (1 s) time-out and the update falls back — correct, but it makes the rehearsal
-        # crawl.  The rehearsal is about the exchange path, not the schedule: event-ordered kernels from the start.
-        env.setdefault("BOSS_NO_CHAIN", "1")
+        # (several processes on one GPU take turns on its hardware queues: where the resident chain of an update cannot run, its
+        # waits give up after their size-derived budget — tens of milliseconds, once per process — and the library carries on with
+        # the simpler schedule; the rehearsal runs the shipped defaults)
     import __graft_entry__ as entry
     entry.compile_library()                                # once, here (hipcc only: nothing is loaded, no GPU call)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus))
@@ -337,6 +344,12 @@ def main():
     backend = os.environ.get("BOSS_BENCH_BACKEND", "nccl")
     n_vis = torch.cuda.device_count()
     dev_index = local_rank if local_rank < n_vis else local_rank % max(n_vis, 1)
+    if world > n_vis and backend == "nccl":
+        # RCCL refuses two ranks on one device: with fewer GPUs than ranks only the gloo rehearsal is possible
+        if "BOSS_BENCH_BACKEND" in os.environ:
+            raise SystemExit(f"--gpus {world}: the runtime shows {n_vis} GPU(s); RCCL needs one per rank (BOSS_BENCH_BACKEND=gloo rehearses on fewer)")
+        backend = "gloo"
+        os.environ["BOSS_BENCH_REHEARSAL"] = "1"
     torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
@@ -436,12 +449,21 @@ def main():
     # ---- per-kernel HIP-event timing of the dominant kernels (separate pass, events on the library's stream)
     roof = roof_potrf = None
     if rank == 0:
+        # (a) the dominant kernel inside the UNSERIALISED step: the update runs as always (resident chain, side stream), the event
+        # pair is switched on for the acquisition call alone — two hipEventRecord around predict_kernel on the library's stream
+        api.prof_reset(dev)
+        for i in range(10):
+            gp.update(lam, 1.0, 0.05 + 1e-4 * (i % 7))
+            api.prof_enable(dev, True)
+            api.acq_ei([[gp]], cand, [1.0], None, best, want_acq=False)
+            api.prof_enable(dev, False)
+        ms_pred, n_pred = api.prof_get(dev, "predict")
+        # (b) the factorisation's kernel classes, from a serialised pass (events around every launch: one stream, no look-ahead)
         api.prof_enable(dev, True)
         api.prof_reset(dev)
         reps = 5
         for i in range(reps):
             step(i, exchange=False)          # rank-0-only pass: must not contain a collective
-        ms_pred, n_pred = api.prof_get(dev, "predict")
         ms_syrk, n_syrk = api.prof_get(dev, "potrf_syrk")
         ms_diag, n_diag = api.prof_get(dev, "potrf_diag")
         ms_trsm, n_trsm = api.prof_get(dev, "potrf_trsm")
@@ -453,7 +475,13 @@ def main():
                 "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 16-B/lane correction] + WRITE_SIZE, x1024)",
                 "traffic_source": traffic_src,
-                "avg_launch_ms": ms_pred / n_pred, "flops_per_launch": fl_pred}
+                "avg_launch_ms": ms_pred / n_pred, "launches_timed": int(n_pred), "flops_per_launch": fl_pred,
+                "timing": "HIP events around predict_kernel on the library's stream inside unserialised update + acquisition steps "
+                          "(includes the two event records: a few µs); rocprofv3 --kernel-trace average of the same command under profiles/",
+                # a dependence-free fp64 MFMA stream with ONE wave per SIMD (this kernel's register budget) retires 68.3 TFLOP/s
+                # on 256 CUs (profiles/r03_mfma_rate_probe.log; four waves: 76.6)
+                "one_wave_per_simd_issue_rate_tflops": ONE_WAVE_ISSUE_TFLOPS,
+                "frac_vs_one_wave_issue_rate": ach / ONE_WAVE_ISSUE_TFLOPS}
         # the factorisation: N^3/3 over the whole posterior update (two-stream look-ahead; the
         # per-class event times below come from the serialised profiling pass)
         fl_potrf = N_OBS ** 3 / 3
@@ -464,6 +492,19 @@ def main():
                       "ms_per_update": t_upd_s * 1e3,
                       "serialised_ms_diag": ms_diag / reps, "serialised_ms_trsm": ms_trsm / reps,
                       "serialised_ms_syrk": ms_syrk / reps}
+
+    # ---- latency distribution of the posterior update (the resident chain's tail latency): 240 back-to-back updates
+    upd_dist = None
+    if rank == 0:
+        ts = []
+        for i in range(240):
+            t0 = time.perf_counter()
+            gp.update(lam, 1.0, 0.05 + 1e-4 * (i % 7))
+            ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.array(ts)) * 1e3
+        upd_dist = {"n": int(ts.size), "update_ms_p50": float(np.percentile(ts, 50)), "update_ms_p90": float(np.percentile(ts, 90)),
+                    "update_ms_p99": float(np.percentile(ts, 99)), "update_ms_max": float(ts[-1]), "update_ms_min": float(ts[0]),
+                    "update_ms_mean": float(ts.mean())}
 
     # ---- SURVEY §8f rows built beyond the headline path (rank 0, N=1 only; a fraction of a second)
     extras = None
@@ -634,7 +675,7 @@ def main():
                        "parallelism": f"{world} independent GP slices + candidate shards, 16-byte arg-max all-gather over {backend}"},
             "frac_of_fp64_mfma_roofline": {"update": flops_update(N_OBS, D) * upd_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12),
                                            "acq": flops_acq_eval(N_OBS, D) * acq_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12)},
-            "roofline": roof, "roofline_potrf": roof_potrf, "strong_scaling": strong, "strong_scaling_inproc": inproc,
+            "roofline": roof, "roofline_potrf": roof_potrf, "update_latency": upd_dist, "strong_scaling": strong, "strong_scaling_inproc": inproc,
             "batched_updates": batched, "acq_by_M": acq_by_m, "cpu_baseline": cpu, "next_rows": extras,
         }
         if os.environ.get("BOSS_BENCH_REHEARSAL"):

@@ -322,6 +322,7 @@ struct boss_gp {
     bool dinv_used = false;                    // the current block inverses were used by a prediction (see factor_enqueue)
     bool dinv_used_prev = false;               // its value when the pending update was enqueued (restored if that update is repeated)
     bool gated = false;                        // the pending update was enqueued with gate kernels
+    bool chained = false;                      // ... and under the resident panel chain (chain.hpp)
     double* host_res = nullptr;                // pinned: scal[2], info
     double* host_res_dev = nullptr;            // the same memory through its device address (written by small_fit_kernel / potrf_logdet_kernel)
     bool par_in_args = false;                  // this update's hyper-parameters travel in the first kernel's arguments
@@ -494,6 +495,20 @@ extern "C" int boss_prof_get(int device, const char* kernel_class, double* ms_to
     }
     if (ms_total) *ms_total = tot;
     if (launches) *launches = n;
+    return BOSS_OK;
+}
+
+// Host-side walk of potrf_colupd_kernel's workgroup -> strip map (the same colupd_decode the kernel calls): R0/C0/crit of every
+// workgroup of a launch.  No device work: tests/test_abi_and_host.py checks each launch form of the schedule for duplicates.
+extern "C" int boss_debug_colupd_decode(int G, int k, int m, int ncols, int jfirst, int skipdiag, int xblk, int critical,
+                                        int* R0, int* C0, int* crit) {
+    if (G < 1 || !R0 || !C0 || !crit) return fail(BOSS_E_INVALID, "bad argument");
+    for (int t = 0; t < G; ++t) {
+        const ColupdWork w = colupd_decode(t, G, k, m, ncols, jfirst, skipdiag, xblk, critical != 0);
+        R0[t] = w.R0;
+        C0[t] = w.C0;
+        crit[t] = w.crit;
+    }
     return BOSS_OK;
 }
 

@@ -60,7 +60,8 @@ __device__ const unsigned char chain_tile_tab[16][3] = {   // wave -> tile row, 
     {7, 0, 3}, {7, 3, 3}, {7, 6, 2}, {6, 0, 3}, {6, 3, 2}, {6, 5, 2}, {5, 0, 3}, {5, 3, 3},
     {4, 0, 3}, {4, 3, 2}, {3, 0, 2}, {3, 2, 2}, {2, 0, 3}, {1, 0, 2}, {0, 0, 1}, {0, 0, 0}};
 __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int ld, int b, int* __restrict__ info,
-                                                             unsigned long long* __restrict__ sig, unsigned long long base, int wave_s) {
+                                                             unsigned long long* __restrict__ sig, unsigned long long base, int wave_s,
+                                                             unsigned budget) {
     extern __shared__ double smem[];
     int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (as in chain_factor_phase)
     asm volatile("" : "+v"(lane));
@@ -97,15 +98,15 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
     if (wave == 15) {
         // the polling wave: posts every advance until the last panel is out (or the wait gives up: 99 releases everybody)
         if (lane == 0) CTRACE(b, 1);
-        for (int it = 0; it < POLL_SPINS && seen < 8; ++it) {
+        const PollTimer tm(budget);                              // (for all eight panels of the block: a whole step of the chain)
+        for (int it = 0; it < POLL_CAP && seen < 8; ++it) {
             const int mn = poll_strips();
             asm volatile("" ::: "memory");
             if (mn > seen) {
                 seen = mn;
                 if (lane == 0) *seenw = seen;
-                it = 0;
             }
-            if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
+            if (tm.check(it, info)) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (seen < 8) {
@@ -122,7 +123,7 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
     while (jb < 8) {
         if (!dead && seen <= jb) {
             bool got = false;
-            for (int it = 0; it < (POLL_SPINS << 3); ++it) {
+            for (int it = 0; it < POLL_CAP; ++it) {               // (an LDS word of this workgroup: the polling wave posts 99 when it gives up)
                 const int v = *seenw;
                 if (v > jb) {
                     seen = v;
@@ -200,7 +201,7 @@ __device__ __forceinline__ void chain_factor_phase(double* __restrict__ Ab, int 
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __restrict__ A, int ld, int nblk,
                                                                    double* __restrict__ inv16, int* __restrict__ info,
                                                                    unsigned long long* __restrict__ sig, unsigned long long base,
-                                                                   unsigned long long cbase) {
+                                                                   unsigned long long cbase, unsigned budget) {
     extern __shared__ double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __res
         // ---- block b with every panel < b-1 applied: the Gram matrix itself (b = 0, 1: the first follow kernel has started) or
         // tile (b, b) as the critical strips of step b-2's column update stored it (sig[SIGW_CRIT] >= cbase + 8 (b-1))
         if (wave == 0) {
-            const bool ok = b < 2 ? poll_ge(sig + SIGW_WDONE, base + 1, info) : poll_ge(sig + SIGW_CRIT, cbase + 8ull * (b - 1), info);
+            const bool ok = b < 2 ? poll_ge(sig + SIGW_WDONE, base + 1, info, budget) : poll_ge(sig + SIGW_CRIT, cbase + 8ull * (b - 1), info, budget);
             if (lane == 0) {
                 *ctrl = ok ? 1 : -1;
                 ctrl[1] = 0;                                  // (the follower phase's posted panel count)
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __res
             }
         } else {
             CHAIN_CUT_VGPRS();
-            chain_follow_phase(A, ld, b, info, sig, base, wave);
+            chain_follow_phase(A, ld, b, info, sig, base, wave, budget);
         }
         CHAIN_CUT_VGPRS();
         __syncthreads();
@@ -269,7 +270,7 @@ template <bool CRIT>
 __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int k, const double* __restrict__ inv16base,
                                              double* __restrict__ Brow, unsigned long long* __restrict__ prog,
                                              unsigned long long* __restrict__ sig, unsigned long long base, int* __restrict__ info,
-                                             v4d (&xs)[TRSM_NA][64], int& ready, int& drained, int& avail) {
+                                             v4d (&xs)[TRSM_NA][64], int& ready, int& drained, int& avail, unsigned budget) {
     constexpr bool crit = CRIT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -295,7 +296,8 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
     // the path from the chain's last panel to the next diagonal block; the row tiles of the panel (they overwrite live matrix
     // entries: no pattern possible) are still taken behind the word.
     auto ival_poll = [&](int jb, double (&iv)[4]) {
-        for (int it = 0; it < POLL_SPINS; ++it) {
+        const PollTimer tm(budget);
+        for (int it = 0; it < POLL_CAP; ++it) {
             bool miss = false;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -304,7 +306,7 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
             }
             if (!__any(miss)) return;
             if (dead) return;
-            if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
+            if (tm.check(it, info)) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (!dead && lane == 0) {
@@ -325,14 +327,15 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
     auto await = [&](int jb) {                                   // panel jb of block k is out
         if (dead || seen > jb) return;
         if (wave == 0) {
-            for (int i = 0; i < POLL_SPINS; ++i) {
+            const PollTimer tm(budget);
+            for (int i = 0; i < POLL_CAP; ++i) {
                 seen = panels_out(ld_word(sig + SIGW_PANEL));
                 if (seen > jb) {
                     asm volatile("" ::: "memory");
                     if (lane == 0) *(volatile lds_int_t*)&avail = seen;
                     return;
                 }
-                if ((i & 1023) == 1023 && ld_info(info) == INT_MIN) break;
+                if (tm.check(i, info)) break;
                 __builtin_amdgcn_s_sleep(crit ? 1 : 8);
             }
             dead = true;
@@ -342,7 +345,7 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
                 *(volatile lds_int_t*)&avail = 99;               // (releases wave 1)
             }
         } else {
-            for (int i = 0; i < (POLL_SPINS << 3); ++i) {
+            for (int i = 0; i < POLL_CAP; ++i) {                  // (an LDS word of this workgroup: wave 0 posts 99 when it gives up)
                 seen = *(volatile lds_int_t*)&avail;
                 if (seen > jb) {
                     asm volatile("" ::: "memory");
@@ -554,7 +557,7 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
 __global__ __launch_bounds__(TRSM_THREADS) void potrf_follow_kernel(double* __restrict__ A, int ld, int k,
                                                                     const double* __restrict__ inv16base, int row0, int wait_rows,
                                                                     unsigned long long* __restrict__ sig, unsigned long long base,
-                                                                    unsigned long long gateval, int* __restrict__ info) {
+                                                                    unsigned long long gateval, int* __restrict__ info, unsigned budget) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         raise_word(sig + SIGW_WDONE, base + k + 1);
         if (gateval) raise_word(sig + SIGW_GATE, gateval);
@@ -565,19 +568,21 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_follow_kernel(double* __re
     __shared__ int ready, drained, avail;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* Brow = A + (size_t)row0 + (size_t)blockIdx.x * 16 + (size_t)k * BLK * ld;
-    follow_strip<false>(A, ld, k, inv16base, Brow, nullptr, sig, base, info, xs, ready, drained, avail);
+    follow_strip<false>(A, ld, k, inv16base, Brow, nullptr, sig, base, info, xs, ready, drained, avail, budget);
     if (blockIdx.x == 0 && wave == 0 && wait_rows) {
         // block row k+1 (solved by the resident strips) is out: the column update enqueued behind this kernel reads it
         const int lane = threadIdx.x & 63;
-        for (int it = 0; it < POLL_SPINS; ++it) {
+        const PollTimer tm(budget);
+        for (int it = 0; it < POLL_CAP; ++it) {
             unsigned long long v = ~0ull;
             if (lane < 8) v = ld_word(sig + SIGW_PROG + SIGW_PROG_STRIDE * lane);
             if (__all(v >= base + 8ull * k + 8)) break;
-            if ((it & 1023) == 1023 && ld_info(info) == INT_MIN) break;
-            if (it == POLL_SPINS - 1 && lane == 0) {
+            const int st = tm.check(it, info);
+            if (st == 1 && lane == 0) {
                 st_info(info, INT_MIN);
                 note_giveup(7, k);
             }
+            if (st) break;
             __builtin_amdgcn_s_sleep(4);
         }
     }
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_follow_kernel(double* __re
 __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __restrict__ A, int ld, int nblk,
                                                                     const double* __restrict__ inv16base,
                                                                     unsigned long long* __restrict__ sig, unsigned long long base,
-                                                                    unsigned long long cbase, int* __restrict__ info) {
+                                                                    unsigned long long cbase, int* __restrict__ info, unsigned budget) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ v4d xs[TRSM_NA][64];
     __shared__ int ready, drained, avail;
@@ -598,12 +603,12 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __re
     for (int k = 0; k + 1 < nblk; ++k) {
         // tile (k+1, k) carries every panel < k
         bool ok;
-        if (k == 0) ok = poll_ge(sig + SIGW_WDONE, base + 1, info);
-        else ok = poll_ge(sig + SIGW_CRIT, cbase + 8ull * k, info);
+        if (k == 0) ok = poll_ge(sig + SIGW_WDONE, base + 1, info, budget);
+        else ok = poll_ge(sig + SIGW_CRIT, cbase + 8ull * k, info, budget);
         (void)ok;                                                // (gave up: info is marked, carry on without waiting — every loop stays bounded)
         __syncthreads();                                         // xs / ready / drained of the previous step are no longer in use
         double* Brow = A + (size_t)(k + 1) * BLK + (size_t)blockIdx.x * 16 + (size_t)k * BLK * ld;
-        follow_strip<true>(A, ld, k, inv16base, Brow, sig + SIGW_PROG + SIGW_PROG_STRIDE * blockIdx.x, sig, base, info, xs, ready, drained, avail);
+        follow_strip<true>(A, ld, k, inv16base, Brow, sig + SIGW_PROG + SIGW_PROG_STRIDE * blockIdx.x, sig, base, info, xs, ready, drained, avail, budget);
 #ifdef BOSS_CHAIN_TRACE
         if (blockIdx.x == 0 && threadIdx.x == 64) g_ctrace[(k & 63) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 #endif

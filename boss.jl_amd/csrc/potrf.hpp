@@ -155,15 +155,36 @@ constexpr int SIGW_GATE = 0, SIGW_BULK = 3, SIGW_PANEL = 16, SIGW_WDONE = 32, SI
 // who gave up first (diagnostics: BOSS_CHAIN_VERBOSE prints it when an update falls back): code * 1000 + detail
 __device__ int g_giveup = 0;
 __device__ __forceinline__ void note_giveup(int code, int detail) { atomicCAS(&g_giveup, 0, code * 1000 + (detail & 511)); }
-constexpr int POLL_SPINS = 1 << 20;                        // ≈ 1 s: something lets only one kernel run at a time -> info = INT_MIN, the host falls back
+// Bounded waits.  Every wait of the cross-kernel protocols gives up when `budget` ticks of the constant 100 MHz clock (s_memrealtime)
+// have passed since the wait began: the host derives the budget from the size of the system (≈ 20× the expected update time, at
+// least 20 ms: poll_budget_ticks, host_factor.inc), so that a caller whose device cannot run the kernels side by side (another
+// process holding the CUs, a tool that serialises the queues) loses tens of milliseconds ONCE, not a second per wait.  The clock is
+// read every 64th poll; POLL_CAP bounds the loop count whatever the clock does.  A wait that gives up marks the factorisation
+// (info = INT_MIN: gp_finish repeats it on the next simpler schedule) and every other waiter notices the mark within 64 polls.
+constexpr int POLL_CAP = 1 << 26;
+struct PollTimer {
+    unsigned long long t0;
+    unsigned budget;
+    __device__ __forceinline__ explicit PollTimer(unsigned b) : t0(__builtin_amdgcn_s_memrealtime()), budget(b) {}
+    __device__ __forceinline__ bool expired() const { return __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)budget; }
+    // every 64th poll: 1 = out of time, 2 = somebody else gave up already, 0 = keep polling
+    __device__ __forceinline__ int check(int i, const int* info) const {
+        if ((i & 63) != 63) return 0;
+        if (ld_info(info) == INT_MIN) return 2;
+        return expired() ? 1 : 0;
+    }
+};
 // One wave waits until *w >= v (wave-uniform).  false: gave up (timeout, or another waiter already marked the factorisation).
-__device__ __forceinline__ bool poll_ge(const unsigned long long* w, unsigned long long v, int* info) {
-    for (int i = 0; i < POLL_SPINS; ++i) {
+__device__ __forceinline__ bool poll_ge(const unsigned long long* w, unsigned long long v, int* info, unsigned budget) {
+    const PollTimer tm(budget);
+    for (int i = 0; i < POLL_CAP; ++i) {
         if (ld_word(w) >= v) {
             asm volatile("" ::: "memory");
             return true;
         }
-        if ((i & 1023) == 1023 && ld_info(info) == INT_MIN) return false;
+        const int st = tm.check(i, info);
+        if (st == 2) return false;
+        if (st == 1) break;
         __builtin_amdgcn_s_sleep(1);
     }
     if ((threadIdx.x & 63) == 0) {
@@ -437,13 +458,15 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ smem, dou
 
 // Gate in front of a kernel on another stream: one lane polls a sequence word until it reaches v (the producer stream's
 // next kernel stores it at its entry, see potrf_diag_kernel), sleeping ≈0.4 µs between polls so that it does not disturb the
-// waves it shares a SIMD with.  The spin is bounded (≈1 s); a timeout marks the factorisation as failed (info = INT_MIN)
+// waves it shares a SIMD with.  The spin is bounded (PollTimer); a timeout marks the factorisation as failed (info = INT_MIN)
 // instead of letting the gated kernel run on unfinished operands.
 __global__ __launch_bounds__(64) void potrf_gate_kernel(unsigned long long* __restrict__ sig, unsigned long long v,
-                                                        int* __restrict__ info) {
+                                                        int* __restrict__ info, unsigned budget) {
     if (threadIdx.x != 0) return;
-    for (int i = 0; i < (1 << 21); ++i) {
+    const PollTimer tm(budget);
+    for (int i = 0; i < POLL_CAP; ++i) {
         if (__hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return;
+        if ((i & 63) == 63 && tm.expired()) break;
         __builtin_amdgcn_s_sleep(16);
     }
     info[0] = INT_MIN;
@@ -462,17 +485,19 @@ __global__ __launch_bounds__(64) void potrf_publish_kernel(unsigned long long* _
 // resident chain the column updates arrive early and wait tens of microseconds, and a thousand waves polling one line in memory
 // slowed the bulk update they were waiting for; the others wait at the barrier.  A workgroup that had to wait re-acquires (its
 // kernel started before the producer ended).
-__device__ __forceinline__ void wait_word(unsigned long long* w, unsigned long long v, int* info) {
+__device__ __forceinline__ void wait_word(unsigned long long* w, unsigned long long v, int* info, unsigned budget) {
     if (!w) return;
     __shared__ int waited_s;
     if (threadIdx.x == 0) {
         bool ok = false, waited = false;
-        for (int i = 0; i < (1 << 21); ++i) {
+        const PollTimer tm(budget);
+        for (int i = 0; i < POLL_CAP; ++i) {
             if (ld_word(w) >= v) {
                 ok = true;
                 break;
             }
             waited = true;
+            if (tm.check(i, info)) break;
             __builtin_amdgcn_s_sleep(16);
         }
         if (!ok) {
@@ -1281,56 +1306,33 @@ __global__ __launch_bounds__(256, 2) void potrf_syrk_kernel(double* __restrict__
     }
 }
 
-// skipdiag: the four strips of tile (k+1, k+1) are left out — the persistent chain applies panel k to that tile itself (chain.hpp);
-// xblk >= 0: four extra strips update the diagonal tile (xblk, xblk) with the same panel(s), so that every diagonal tile has
-// received every panel but the last one a whole step before its own factorisation (even steps: xblk = k+2; odd steps: k+3,
-// which the bulk update then leaves out).
-__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
-                                                              int m, int ncols, int jfirst, int npan,
-                                                              unsigned long long* wword, unsigned long long wval, int* info,
-                                                              int skipdiag, int xblk, unsigned long long* critw) {
-#ifdef BOSS_CHAIN_TRACE
-    if (threadIdx.x == 0) atomicMin(&g_cutrace[(k & 63) * 4 + 0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    struct TraceEnd { int k; __device__ ~TraceEnd() { if (threadIdx.x == 0) atomicMax(&g_cutrace[(k & 63) * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } trace_end_{k};
-#endif
-    wait_word(wword, wval, info);                            // (look-ahead schedule: the bulk update that wrote these columns before)
-    // npan = 2: apply the TWO panels k-1, k (K = 256) — the odd steps of the paired look-ahead schedule
-    // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
-    // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
-    // (used for the last steps, where one small launch beats the two-stream choreography).
-    __builtin_amdgcn_s_setprio(3);           // a chain kernel: its waves win issue arbitration over co-resident bulk-update waves
-    double* A = Abase + (size_t)blockIdx.z * bstride;
-    int t = blockIdx.x;
-    if (critw) {
+// Workgroup -> strip of potrf_colupd_kernel (host-callable: tests/test_abi_and_host.py walks every launch form of the schedule
+// through boss_debug_colupd_decode and checks that each 32×128 strip is taken by exactly ONE workgroup — syrk_tile is a plain
+// read-modify-write, two workgroups on one strip would apply the panel twice).
+//   R0 < 0: nothing to do;  crit: one of the eight critical strips of the chain schedule.
+struct ColupdWork {
+    int R0, C0, crit;
+};
+__host__ __device__ inline ColupdWork colupd_decode(int t, int G, int k, int m, int ncols, int jfirst, int skipdiag, int xblk, bool critical) {
+    if (m < 2) critical = false;                             // no block row k+2: the swap below would not be a permutation (m == 1, a grid
+                                                             // of 5: every workgroup landed on the δ^T strip of the last block column)
+    if (critical) {
         // dispatch order: the eight critical strips first — tile (k+2, k+1) = strips 4..7 of this list, tile (k+2, k+2) = the extra
         // strips at its end (even steps) or the first four strips of the second column — swapped with strips 0..3 (the left-out
         // diagonal tile: nothing to do) and 4..7
-        const int G = (int)gridDim.x;
         const int d0 = (xblk == k + 2) ? G - 4 : 4 * m + 1;
         if (t < 4) t = 4 + t;
         else if (t < 8) t = d0 + (t - 4);
         else if (t >= d0 && t < d0 + 4) t = t - d0;
     }
-    // critw: the strips of tiles (k+2, k+1) and (k+2, k+2) — what the resident chain needs first for step k+1 — store write-through
-    // and count themselves in (eight per step); the resident kernels start on those tiles while the rest of this launch is still running
-    auto crit_done = [&]() {
-        drain_stores();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(critw), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    if (xblk >= 0 && t >= (int)gridDim.x - 4) {
-        const int R0 = xblk * BLK + (t - ((int)gridDim.x - 4)) * 32;
-        if (critw && xblk == k + 2) {
-            if (npan == 2) syrk_tile<RhsG, true>(A, ld, k - 1, R0, xblk * BLK, 2 * BLK);
-            else syrk_tile<RhsG, true>(A, ld, k, R0, xblk * BLK);
-            crit_done();
-            return;
-        }
-        if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, R0, xblk * BLK, 2 * BLK);
-        else syrk_tile<RhsG>(A, ld, k, R0, xblk * BLK);
-        return;
+    if (xblk >= 0 && t >= G - 4) {
+        ColupdWork w = {xblk * BLK + (t - (G - 4)) * 32, xblk * BLK, (critical && xblk == k + 2) ? 1 : 0};
+        return w;
     }
-    if (skipdiag && t < 4) return;                            // column k+1's strips 0..3 = its diagonal tile
+    if (skipdiag && t < 4) {                                  // column k+1's strips 0..3 = its diagonal tile
+        ColupdWork w = {-1, -1, 0};
+        return w;
+    }
     int j = jfirst;                                           // first trailing block column handled (0 = column k+1)
     if (ncols > 1) {
         // column j has 4*(m-j)+1 strips
@@ -1341,14 +1343,44 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     }
     const int nstr = 4 * (m - j);
     const int R0 = (t < nstr) ? (k + 1 + j) * BLK + t * 32 : (k + 1 + m) * BLK;
-    if (critw && t < nstr && R0 / BLK == k + 2 && j <= 1) {       // tile (k+2, k+1) or (k+2, k+2)
-        if (npan == 2) syrk_tile<RhsG, true>(A, ld, k - 1, R0, (k + 1 + j) * BLK, 2 * BLK);
-        else syrk_tile<RhsG, true>(A, ld, k, R0, (k + 1 + j) * BLK);
-        crit_done();
+    ColupdWork w = {R0, (k + 1 + j) * BLK, (critical && t < nstr && R0 / BLK == k + 2 && j <= 1) ? 1 : 0};   // tile (k+2, k+1) or (k+2, k+2)
+    return w;
+}
+
+// skipdiag: the four strips of tile (k+1, k+1) are left out — the persistent chain applies panel k to that tile itself (chain.hpp);
+// xblk >= 0: four extra strips update the diagonal tile (xblk, xblk) with the same panel(s), so that every diagonal tile has
+// received every panel but the last one a whole step before its own factorisation (even steps: xblk = k+2; odd steps: k+3,
+// which the bulk update then leaves out).
+__global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
+                                                              int m, int ncols, int jfirst, int npan,
+                                                              unsigned long long* wword, unsigned long long wval, int* info,
+                                                              int skipdiag, int xblk, unsigned long long* critw, unsigned budget) {
+#ifdef BOSS_CHAIN_TRACE
+    if (threadIdx.x == 0) atomicMin(&g_cutrace[(k & 63) * 4 + 0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    struct TraceEnd { int k; __device__ ~TraceEnd() { if (threadIdx.x == 0) atomicMax(&g_cutrace[(k & 63) * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } trace_end_{k};
+#endif
+    wait_word(wword, wval, info, budget);                    // (look-ahead schedule: the bulk update that wrote these columns before)
+    // npan = 2: apply the TWO panels k-1, k (K = 256) — the odd steps of the paired look-ahead schedule
+    // 32×128 tiles.  ncols = 1: only block column k+1 (look-ahead: the next panel) — 4 strips per
+    // 128-row block (m blocks) + one strip of the δ^T rows.  ncols = m: the whole trailing triangle
+    // (used for the last steps, where one small launch beats the two-stream choreography).
+    __builtin_amdgcn_s_setprio(3);           // a chain kernel: its waves win issue arbitration over co-resident bulk-update waves
+    double* A = Abase + (size_t)blockIdx.z * bstride;
+    if (m < 2) critw = nullptr;                              // no block row k+2: no critical strips (see colupd_decode)
+    const ColupdWork w = colupd_decode((int)blockIdx.x, (int)gridDim.x, k, m, ncols, jfirst, skipdiag, xblk, critw != nullptr);
+    if (w.R0 < 0) return;                                     // a left-out strip (tile (k+1, k+1) under the chain schedule)
+    // critical strips — tiles (k+2, k+1) and (k+2, k+2), what the resident chain needs first for step k+1 — store write-through
+    // and count themselves in (eight per step); the resident kernels start on those tiles while the rest of this launch is still running
+    if (w.crit) {
+        if (npan == 2) syrk_tile<RhsG, true>(A, ld, k - 1, w.R0, w.C0, 2 * BLK);
+        else syrk_tile<RhsG, true>(A, ld, k, w.R0, w.C0);
+        drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(critw), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, R0, (k + 1 + j) * BLK, 2 * BLK);
-    else syrk_tile<RhsG>(A, ld, k, R0, (k + 1 + j) * BLK);
+    if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, w.R0, w.C0, 2 * BLK);
+    else syrk_tile<RhsG>(A, ld, k, w.R0, w.C0);
 }
 
 // Block-row variant for boss_gp_append: behind panel k update ONLY block row kb (4 strips of

@@ -213,3 +213,66 @@ def test_integration_doc_shows_the_shipped_julia_glue():
         assert hdr, name
         nargs = 0 if hdr.group(1).strip() in ("", "void") else hdr.group(1).count(",") + 1
         assert len(types) == nargs, (name, len(types), nargs)
+
+
+def test_column_update_takes_every_strip_exactly_once():
+    """potrf_colupd_kernel applies `C -= P P^T` to 32×128 strips with a plain read-modify-write: two workgroups on one
+    strip would subtract the panel twice.  The workgroup -> strip map (colupd_decode, shared by the kernel and this
+    host walk) is checked for every launch form potrf_enqueue issues (host_factor.inc) — including the chain schedule's
+    last tail step (m == 1, a grid of 5), where the critical-strip swap used to send all five workgroups to the δ^T strip."""
+    import ctypes as C
+    from boss_jl_amd import api
+    lib = api.load_library()
+    fn = lib.boss_debug_colupd_decode
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_int)] * 3
+    BLK = 128
+
+    def walk(G, k, m, ncols, jfirst, skipdiag, xblk, critical):
+        R0, C0, cr = (C.c_int * G)(), (C.c_int * G)(), (C.c_int * G)()
+        assert fn(G, k, m, ncols, jfirst, skipdiag, xblk, critical, R0, C0, cr) == 0
+        return [(R0[t], C0[t], cr[t]) for t in range(G)]
+
+    def expect(k, m, cols, skipdiag, xblk, skip_first_diag_of=None):
+        want = set()
+        for j in cols:
+            for t in range(4 * (m - j)):
+                want.add(((k + 1 + j) * BLK + 32 * t, (k + 1 + j) * BLK))
+            want.add(((k + 1 + m) * BLK, (k + 1 + j) * BLK))              # δ^T strip of the column
+        if skipdiag:
+            for t in range(4):
+                want.discard(((k + 1 + cols[0]) * BLK + 32 * t, (k + 1 + cols[0]) * BLK))
+        if xblk >= 0:
+            for t in range(4):
+                want.add((xblk * BLK + 32 * t, xblk * BLK))
+        return want
+
+    def check(work, want, ncrit, first_eight_crit):
+        done = [(r, c) for r, c, _ in work if r >= 0]
+        assert len(done) == len(set(done)), "a strip is taken by more than one workgroup"
+        assert set(done) == want
+        assert sum(cr for r, _, cr in work if r >= 0) == ncrit
+        if first_eight_crit:                                               # the critical strips are dispatched first
+            assert all(cr == 1 and r >= 0 for r, _, cr in work[:8])
+
+    for chain in (0, 1):
+        for k in (0, 3, 10):
+            for m in range(1, 14):
+                # even step of the paired phase / plain look-ahead step: column k+1 (+ tile (k+2, k+2) under the chain schedule)
+                xblk = k + 2 if (chain and m >= 2) else -1
+                G = 4 * m + 1 + (4 if xblk >= 0 else 0)
+                check(walk(G, k, m, 1, 0, chain, xblk, chain), expect(k, m, [0], chain, xblk), 8 if (chain and m >= 2) else 0, chain and m >= 2)
+                # odd step: columns k+1, k+2 (+ tile (k+3, k+3))
+                nc = 2 if m >= 2 else 1
+                xblk = k + 3 if (chain and m - 2 > 0) else -1
+                G = (4 * m + 1) + (4 * (m - 1) + 1 if nc == 2 else 0) + (4 if xblk >= 0 else 0)
+                check(walk(G, k, m, nc, 0, chain, xblk, chain), expect(k, m, list(range(nc)), chain, xblk), 8 if (chain and m >= 2) else 0,
+                      chain and m >= 2)
+                # single-stream tail: the whole trailing triangle
+                G = 2 * m * (m + 1) + m
+                check(walk(G, k, m, m, 0, chain, -1, chain), expect(k, m, list(range(m)), chain, -1), 8 if (chain and m >= 2) else 0,
+                      chain and m >= 2)
+                # near part of a split bulk update: columns k+3, k+4 without (k+3, k+3), plus tile (k+5, k+5); never critical
+                if m >= 5:
+                    G = (4 * (m - 2) + 1) + (4 * (m - 3) + 1) + 4
+                    check(walk(G, k, m, 2, 2, 1, k + 5, 0), expect(k, m, [2, 3], 1, k + 5), 0, False)

@@ -1,0 +1,112 @@
+"""Soak tests of the resident panel chain (csrc/chain.hpp), pytest -m gpu.
+
+The chain is a lock-free protocol between workgroups that run at the same time (write-through stores, sequence words, data-pattern
+polling).  Its arithmetic order is fixed — whichever of its paths a wave takes (one or two panels per round trip, lockstep or late
+strips) issues the same MFMAs on the same operands in the same order — so repeated updates under the same hyper-parameters must be
+BIT-IDENTICAL: logpdf and the whole factor.  A hand-off that lets a consumer read a tile too early, or apply a panel twice, shows
+up as a changed bit long before it exceeds a parity tolerance.  (Replaces the schedule around AbstractGPs.posterior's cholesky,
+/root/reference/src/models/gaussian_process.jl:199-211.)
+"""
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = [0.05 + 1e-4 * i for i in range(7)]
+
+
+@pytest.fixture(scope="module")
+def api():
+    entry.build()
+    from boss_jl_amd import api as a
+    a.load_library()
+    assert a.device_count() >= 1
+    return a
+
+
+def make(d, N, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(2 * np.pi * X).sum(0) / np.sqrt(d) + 0.05 * rng.standard_normal(N)
+    return X, y
+
+
+def bits(x):
+    return struct.pack("<d", float(x))
+
+
+def soak(api, N, updates, with_load):
+    d = 8
+    X, y = make(d, N, 11)
+    lam = np.full(d, 0.5)
+    g = api.GP(X, y, "matern52")
+    stop = threading.Event()
+    load_calls = [0]
+    load_err = []
+    th = None
+    if with_load:
+        # a second host thread keeps the device busy with 8192-candidate acquisitions on ANOTHER handle of the same device
+        # context: its kernels share the main stream, the CUs and the L2 with the chain
+        X2, y2 = make(d, 2048, 12)
+        g2 = api.GP(X2, y2, "matern52")
+        g2.update(lam, 1.0, 0.05)
+        cand = api.Candidates(np.random.default_rng(13).uniform(0, 1, (d, 8192)))
+        best = float(y2.max())
+        ref = api.acq_ei([[g2]], cand, [1.0], None, best, want_acq=False)[1:]
+
+        def load():
+            try:
+                while not stop.is_set():
+                    got = api.acq_ei([[g2]], cand, [1.0], None, best, want_acq=False)[1:]
+                    if got != ref:
+                        load_err.append((got, ref))
+                        return
+                    load_calls[0] += 1
+            except Exception as e:                               # surfaces in the main thread's assertion
+                load_err.append(repr(e))
+
+        th = threading.Thread(target=load, daemon=True)
+        th.start()
+    first_lp, first_L = {}, {}
+    changed = []
+    try:
+        for i in range(updates):
+            lv = i % len(LEVELS)
+            lp = g.update(lam, 1.0, LEVELS[lv])
+            if lv not in first_lp:
+                first_lp[lv] = lp
+                first_L[lv] = g.factor()
+            elif bits(lp) != bits(first_lp[lv]):
+                changed.append((i, lv, lp, first_lp[lv]))
+            # the whole factor of every level once more near the end of the run
+            if i >= updates - len(LEVELS):
+                L, z = g.factor()
+                if not (np.array_equal(L, first_L[lv][0]) and np.array_equal(z, first_L[lv][1])):
+                    changed.append((i, lv, "factor"))
+    finally:
+        stop.set()
+        if th is not None:
+            th.join(timeout=60)
+    assert not load_err, load_err[:2]
+    assert not changed, f"{len(changed)} of {updates} updates differ from the first occurrence of their level: {changed[:4]}"
+    if with_load:
+        assert load_calls[0] >= 3, load_calls                      # the load really ran beside the updates
+    g.close()
+    return load_calls[0]
+
+
+@pytest.mark.parametrize("N", [1408, 4096])
+def test_repeated_updates_are_bit_identical(api, N):
+    """500 updates cycling 7 noise levels: every repeat of a level equals its first occurrence bit for bit."""
+    soak(api, N, 500, with_load=False)
+
+
+@pytest.mark.parametrize("N", [1408, 4096])
+def test_repeated_updates_are_bit_identical_under_load(api, N):
+    """The same while a second host thread runs 8192-candidate acquisitions on another handle of the device."""
+    soak(api, N, 500, with_load=True)
