@@ -618,6 +618,34 @@ def main():
         batched["config5_512xN1024"] = {"factorisations_per_sec": S5 / dt, "ms_per_call": dt * 1e3, "tflops": S5 * flops_update(N5, D) / dt / 1e12,
                                         "frac_of_fp64_mfma_peak": S5 * flops_update(N5, D) / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                         "all_positive_definite": bool((st5 == 0).all())}
+        # BASELINE configs[4] end to end: the 512 posteriors RESIDENT out of one batched factorisation (boss_gp_fit_batch), then the
+        # acquisition averaged over all of them at 8192 candidates (one prediction launch over candidate tiles × samples)
+        t0 = time.perf_counter()
+        gps5, ll5b, st5b = api.fit_batch(X5, y5, KERNEL, lam5, amp5, sig5, device=dev)
+        t_fit_first = time.perf_counter() - t0
+        for g5 in gps5:
+            g5.close()
+        t0 = time.perf_counter()
+        gps5, ll5b, st5b = api.fit_batch(X5, y5, KERNEL, lam5, amp5, sig5, device=dev)
+        t_fit = time.perf_counter() - t0
+        h5 = [[g5] for g5 in gps5]
+        best5 = float(y5.max())
+        api.acq_ei(h5, cand, [1.0], None, best5, want_acq=False)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            _, am5, mx5 = api.acq_ei(h5, cand, [1.0], None, best5, want_acq=False)
+        t_acq5 = (time.perf_counter() - t0) / 2
+        fl5 = S5 * M_CAND * flops_acq_eval(N5, D)
+        batched["config5_acq_S512"] = {"fit_batch_ms": t_fit * 1e3, "fit_batch_first_call_ms": t_fit_first * 1e3,
+                                       "fit_tflops": S5 * flops_update(N5, D) / t_fit / 1e12,
+                                       "all_positive_definite": bool((st5b == 0).all()),
+                                       "loglike_equal_to_loglike_batch": bool(np.array_equal(ll5b, ll5)),
+                                       "resident_posteriors": len(gps5), "candidates": M_CAND,
+                                       "ms_per_averaged_acquisition": t_acq5 * 1e3, "evals_per_sec": S5 * M_CAND / t_acq5,
+                                       "tflops": fl5 / t_acq5 / 1e12, "frac_of_fp64_mfma_peak": fl5 / t_acq5 / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                       "argmax": [int(am5), float(mx5)]}
+        for g5 in gps5:
+            g5.close()
         # acquisition over M candidates of the N=4096 posterior: the first call on a fresh factorisation (what one step of a BO
         # loop or one shard of configs[2] at G = 8192/M GPUs pays) and a later call on the same factorisation
         acq_by_m = {}

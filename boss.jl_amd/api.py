@@ -52,6 +52,8 @@ SIGNATURES = {
                                         C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
     "boss_gp_loglike_grad_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
                                              C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_int)]),
+    "boss_gp_fit_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_ucp,
+                                    C.c_int, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_void_p), _c_dp, C.POINTER(C.c_int)]),
     "boss_gp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_gp_predict_grad": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
                                        C.POINTER(C.c_long)]),
@@ -480,6 +482,45 @@ def fit(X, y, kernel, lengthscale, amplitude, noise_std, mean_X=None, discrete=N
     g = GP.__new__(GP)
     g.d, g.N, g.device, g.kernel, g._h, g.logpdf = d, N, device, _kernel_id(kernel), h, out.value
     return g
+
+
+def fit_batch(X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=None, discrete=None, device: int = 0):
+    """S resident posteriors of one output slice from ONE batched factorisation (boss_gp_fit_batch): what
+    `model_posterior.(Ref(model), params, Ref(data))` builds for the S samples of a BI fit (src/posterior.jl:15-19).
+    lengthscales is d×S.  Returns (gps[S], logpdf[S], status[S]); members with status != 0 are unfitted handles."""
+    X = _f64(X, 2)
+    y = _f64(np.asarray(y).reshape(-1), 1)
+    lam = _f64(lengthscales, 2)
+    d, N = X.shape
+    S = lam.shape[1]
+    if lam.shape[0] != d:
+        raise BossError(BOSS_E_INVALID, "lengthscales must be d×S")
+    amp = _f64(np.asarray(amplitudes).reshape(-1), 1)
+    sig = _f64(np.asarray(noise_stds).reshape(-1), 1)
+    if amp.shape[0] != S or sig.shape[0] != S:
+        raise BossError(BOSS_E_INVALID, "amplitudes and noise_stds must have one entry per set")
+    stride = 0
+    m = None
+    if mean_X is not None:
+        m = np.asarray(mean_X, dtype=np.float64)
+        if m.ndim == 2:
+            m = np.ascontiguousarray(m)
+            stride = N
+        else:
+            m = np.ascontiguousarray(m.reshape(-1))
+    disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
+    hs = (C.c_void_p * S)()
+    ll = np.zeros(S)
+    st = np.zeros(S, dtype=np.int32)
+    _check(load_library().boss_gp_fit_batch(device, _kernel_id(kernel), d, N, _dp(X), _dp(y), _dp(m), stride, _ucp(disc), S,
+                                            _dp(lam), _dp(amp), _dp(sig), hs, _dp(ll), st.ctypes.data_as(C.POINTER(C.c_int))))
+    gps = []
+    for s in range(S):
+        g = GP.__new__(GP)
+        g.d, g.N, g.device, g.kernel, g._h = d, N, device, _kernel_id(kernel), C.c_void_p(hs[s])
+        g.logpdf = float(ll[s]) if st[s] == 0 else None
+        gps.append(g)
+    return gps, ll, st
 
 
 def loglike_batch(X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=None, discrete=None, device: int = 0,

@@ -69,6 +69,18 @@ __global__ void ei_accumulate_kernel(const double* __restrict__ mu, const double
     acq_sum[j] += ei_value(mu, var, ldm, j, par, coefs_dev, ymax_dev);
 }
 
+// The same over samples s0 .. s1-1 whose moments lie sstride apart (the batched prediction of a set of posteriors), added in
+// ascending sample order — the order of the launch-per-sample loop, so both give the same sum bit for bit.
+__global__ void ei_accumulate_set_kernel(const double* __restrict__ mu, const double* __restrict__ var, size_t sstride, int ldm, int M,
+                                         int s0, int s1, EiPar par, const double* __restrict__ coefs_dev,
+                                         const double* __restrict__ ymax_dev, double* __restrict__ acq_sum) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double a = acq_sum[j];
+    for (int s = s0; s < s1; ++s) a += ei_value(mu + (size_t)s * sstride, var + (size_t)s * sstride, ldm, j, par, coefs_dev, ymax_dev);
+    acq_sum[j] = a;
+}
+
 // K9 arg-max (Julia argmax: first index of the maximum, NaN counts as the largest value).
 __device__ __forceinline__ bool better(double a, long ia, double b, long ib) {
     const bool an = a != a, bn = b != b;

@@ -97,7 +97,7 @@ struct Ctx {
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
     std::vector<hipEvent_t> ev_pool;
-    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC, few;
+    Workspace vscratch, csc, pred, acq, batchA, batchX, batchMisc, craw, lgA, lgB, lgC, few, setdesc, setmom;
     // batched likelihood gradients: the gradient passes of consecutive sets rotate over LLG_BANKS streams, each with its
     // own bank of workspaces (bank 0 = the main stream and lgA/lgB/lgC)
     static constexpr int LLG_BANKS = 4;
@@ -204,6 +204,8 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)predict_kernel_set<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)grad_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -307,8 +309,19 @@ struct ProfScope {
 // ------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------
+// S posteriors of one output slice fitted as a batch (boss_gp_fit_batch): one device slab and one pinned block for all of them;
+// the members are ordinary handles whose arrays are views into the slab (boss_gp::set) — the slab goes when the last member does.
+struct boss_gpset {
+    Ctx* ctx = nullptr;
+    std::atomic<int> refs{0};
+    void* slab = nullptr;
+    void* host_block = nullptr;
+};
+
 struct boss_gp {
     Ctx* ctx = nullptr;
+    boss_gpset* set = nullptr;                 // member of a batch-fitted set: Xraw, y (shared with its siblings), Xsc, mean, A, inv16, Dinv, Dinv2, invlam, scal,
+                                               // host_res, host_par are views — never freed one by one, detached (gp_own) before anything grows or rewrites the data
     int kernel = 0, d = 0, N = 0, Np = 0, nblk = 0, ld = 0;
     double *Xraw = nullptr, *Xsc = nullptr, *y = nullptr, *mean = nullptr, *A = nullptr;
     double *LT = nullptr, *DT2 = nullptr, *avec = nullptr;   // gradients: transposed factor, transposed 256×256 inverses, a = L⁻ᵀz (lazily)

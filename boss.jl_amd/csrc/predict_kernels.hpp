@@ -29,14 +29,15 @@ struct PredictLds {
 // B operand is the R tile in LDS.  Three barriers per row block, none inside the GEMMs.
 // PRE: the right-hand side K* is not evaluated here but was written to the workgroup's V slab beforehand
 // (gradient-observation posteriors, aug_kstar_kernel); block ib's rows are consumed before V_ib overwrites them.
-template <class G, bool PRE = false>
-__global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
-                                                      const double* __restrict__ Dinv,
-                                                      const double* __restrict__ Xsc,
-                                                      const double* __restrict__ Csc, int d, int Mp, int kern,
-                                                      double amp2, double* __restrict__ Vscratch,
-                                                      const double* __restrict__ mean_s, int M,
-                                                      double* __restrict__ mu_out, double* __restrict__ var_out, int dbg_arg) {
+// predict_body: the work of one workgroup = candidate tile `tile` (BN candidates) of one posterior, V = its own slab.
+template <class G, bool PRE>
+__device__ __forceinline__ void predict_body(const double* __restrict__ A, int ld, int Np, int N,
+                                             const double* __restrict__ Dinv,
+                                             const double* __restrict__ Xsc,
+                                             const double* __restrict__ Csc, int d, int Mp, int kern,
+                                             double amp2, double* __restrict__ V,
+                                             const double* __restrict__ mean_s, int M,
+                                             double* __restrict__ mu_out, double* __restrict__ var_out, int dbg_arg, int tile) {
     // timing experiments (skip GEMM1 / GEMM2 / K* / the V store) exist only in -DBOSS_EXPERIMENTS builds; the shipped
     // library compiles the switches away (dbg_arg is ignored)
 #ifdef BOSS_EXPERIMENTS
@@ -53,8 +54,7 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar wave index (see gemm_f64.hpp)
     const int wr = wave, wc = 0;
-    const int c0 = blockIdx.x * BN;
-    double* V = Vscratch + (size_t)blockIdx.x * Np * BN;
+    const int c0 = tile * BN;
     const int nblk = Np / RB;
 
     // per-thread partial sums live in LDS between row blocks (slot-major [slot][tid]: conflict-free).
@@ -215,6 +215,41 @@ __global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 
             else var_out[j] = amp2 - s + PREDICT_JITTER;
         }
     }
+}
+
+template <class G, bool PRE = false>
+__global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void predict_kernel(const double* __restrict__ A, int ld, int Np, int N,
+                                                      const double* __restrict__ Dinv,
+                                                      const double* __restrict__ Xsc,
+                                                      const double* __restrict__ Csc, int d, int Mp, int kern,
+                                                      double amp2, double* __restrict__ Vscratch,
+                                                      const double* __restrict__ mean_s, int M,
+                                                      double* __restrict__ mu_out, double* __restrict__ var_out, int dbg_arg) {
+    predict_body<G, PRE>(A, ld, Np, N, Dinv, Xsc, Csc, d, Mp, kern, amp2, Vscratch + (size_t)blockIdx.x * Np * G::BN, mean_s, M, mu_out,
+                         var_out, dbg_arg, (int)blockIdx.x);
+}
+
+// The same for a SET of equally shaped posteriors in one launch: grid = (candidate tiles, posteriors).  The S hyper-parameter
+// samples of a Bayesian-inference model (src/posterior.jl:15-19: one posterior per sample; the acquisition is averaged over them,
+// src/acquisitions/expected_improvement.jl:87-90) share the candidates and differ in factor, scaling and amplitude — S launches of
+// M/32 workgroups each leave most of the chip idle for small M and pay S ramps and tails for large M.
+struct PredSet {
+    const double* A;          // factor (+ z row)
+    const double* Dinv;       // 256×256 (BN = 32) diagonal-block inverses
+    const double* Xsc;        // scaled training points
+    const double* Csc;        // the candidates scaled by this posterior's lengthscales
+    const double* mean_s;     // prior mean at the candidates, or null
+    const double* invlam;     // 1/(λ + 1e-8) of this posterior (scale_cand_set_kernel)
+    double* mu;
+    double* var;
+    double amp2;
+};
+template <class G>
+__global__ __launch_bounds__(G::NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void predict_kernel_set(const PredSet* __restrict__ sets, int ld, int Np, int N,
+                                                      int d, int Mp, int kern, double* __restrict__ Vscratch, int M) {
+    const PredSet ps = sets[blockIdx.y];                     // (uniform: scalar loads)
+    predict_body<G, false>(ps.A, ld, Np, N, ps.Dinv, ps.Xsc, ps.Csc, d, Mp, kern, ps.amp2,
+                           Vscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Np * G::BN, ps.mean_s, M, ps.mu, ps.var, 0, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -10,6 +10,17 @@ check(rc) = rc == 0 ? nothing :
     rc == 4 ? throw(DomainError(NaN, unsafe_string(ccall((:boss_last_error, lib), Cstring, ())))) :
               error(unsafe_string(ccall((:boss_last_error, lib), Cstring, ())))
 kernel_id(k) = k isa BOSS.Matern32Kernel ? 0 : k isa BOSS.Matern52Kernel ? 1 : 2      # SqExponential / Gaussian
+version() = unsafe_string(ccall((:boss_version, lib), Cstring, ()))
+device_count() = (n = Ref{Cint}(); check(ccall((:boss_device_count, lib), Cint, (Ref{Cint},), n)); Int(n[]))
+"All GPUs of the node from this process: contexts + one RCCL communicator per device.  Idempotent; returns (devices, exchanges over RCCL)."
+function init_devices()
+    n = Ref{Cint}(); check(ccall((:boss_init, lib), Cint, (Ref{Cint},), n))
+    nd = Ref{Cint}(); rccl = Ref{Cint}(); check(ccall((:boss_comm_info, lib), Cint, (Ref{Cint}, Ref{Cint}), nd, rccl))
+    return Int(nd[]), rccl[] != 0
+end
+function __init__()
+    atexit(() -> ccall((:boss_shutdown, lib), Cvoid, ()))            # communicators and exchange buffers (handles go with their finalizers)
+end
 
 # ---------------------------------------------------------------- SurrogateModel
 "GaussianProcess whose posterior lives on an MI355X.  Wraps a BOSS.GaussianProcess for its mean, kernel and priors."
@@ -121,10 +132,13 @@ function data_loglike(m::HipGaussianProcess, data::BOSS.ExperimentData)
     end
     means = [mean_vals(BOSS.mean_getindex(m.gp.mean, i), X) for i in eachindex(hs)]   # the GP's prior mean has no parameters
     return function ll_data(p::HipGPParams)                            # the closure keeps `hs` alive; the finalizers free them
-        sum(eachindex(hs)) do i
+        for i in eachindex(hs)                                         # all outputs are enqueued (flag 1 = BOSS_FIT_NO_SYNC) ...
+            check(ccall((:boss_gp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
+                  hs[i].h, Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], means[i], 1, C_NULL))
+        end
+        sum(eachindex(hs)) do i                                        # ... then collected: the device never waits for the host in between
             lp = Ref{Cdouble}()
-            check(ccall((:boss_gp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Cint, Ref{Cdouble}),
-                  hs[i].h, Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], means[i], 0, lp))
+            check(ccall((:boss_gp_sync, lib), Cint, (Ptr{Cvoid}, Ref{Cdouble}), hs[i].h, lp))
             lp[]
         end
     end                                    # exceptions → -Inf via BOSS.safe_data_loglike, as for any model
@@ -196,21 +210,26 @@ end
 # `BIParams` (src/types/parameters.jl:128-146) carries S parameter samples; `model_posterior(model, ::AbstractVector{<:ModelParams},
 # data)` (src/posterior.jl:15-19) broadcasts over them, so `BOSS.model_posterior(problem)` of a problem fitted with TuringBI
 # (ext/TuringExt.jl:88-107 — it only needs the model API above) is a Vector of posteriors = P×S device handles, and
-# `HipBatchAM` averages the acquisition over the S samples on the device (`boss_acq_ei(P, S, …)`).  The S factorisations of one
-# output share (X, y): `model_posteriors_batched` builds them from ONE upload per output instead of S.
+# `HipBatchAM` averages the acquisition over the S samples on the device (`boss_acq_ei(P, S, …)`: all P·S predictions in one launch).
+# The S posteriors of one output share (X, y): `model_posteriors_batched` builds them with ONE `boss_gp_fit_batch` call per output —
+# one upload of (X, y), one batched factorisation, S resident handles.
 function model_posteriors_batched(m::HipGaussianProcess, ps::AbstractVector{<:HipGPParams}, data::BOSS.ExperimentData)
-    X = Matrix{Float64}(data.X); P = size(data.Y, 1)
+    X = Matrix{Float64}(data.X); P = size(data.Y, 1); S = length(ps); k = m.gp.kernel
     slices = [Vector{HipPosteriorSlice}(undef, P) for _ in ps]
     for i in 1:P
         y = Vector{Float64}(data.Y[i, :]); mu = BOSS.mean_getindex(m.gp.mean, i); mv = mean_vals(mu, X)
-        for (s, p) in enumerate(ps)
-            h = Ref{Ptr{Cvoid}}(); lp = Ref{Cdouble}()
-            check(ccall((:boss_gp_fit, lib), Cint,
-                (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble,
-                 Ptr{UInt8}, Ref{Ptr{Cvoid}}, Ref{Cdouble}),
-                m.device, kernel_id(base_kernel(m.gp.kernel)), size(X, 1), size(X, 2), X, y, mv,
-                Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], discrete_flags(m.gp.kernel), h, lp))
-            slices[s][i] = HipPosteriorSlice(Handle(h[]), mu)
+        λ = Matrix{Float64}(reduce(hcat, (p.λ[:, i] for p in ps)))
+        hs = fill(C_NULL, S); lp = Vector{Float64}(undef, S); st = zeros(Cint, S)
+        check(ccall((:boss_gp_fit_batch, lib), Cint,
+            (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint,
+             Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}, Ptr{Cint}),
+            m.device, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, y, mv, 0, discrete_flags(k), S,
+            λ, Float64[p.α[i] for p in ps], Float64[p.σ[i] for p in ps], hs, lp, st))
+        owned = Handle.(hs)                                            # every member is freed by its own finalizer; the shared storage goes with the last
+        bad = findfirst(!=(0), st)                                     # a sample that is not PD throws, as `cholesky` would inside the broadcast
+        isnothing(bad) || (st[bad] == 3 ? throw(PosDefException(bad)) : error("boss_gp_fit_batch: invalid hyper-parameters in sample $bad"))
+        for s in 1:S
+            slices[s][i] = HipPosteriorSlice(owned[s], mu)
         end
     end
     return [BOSS.DefaultModelPosterior(sl) for sl in slices]           # what model_posterior(problem) returns under BIParams
@@ -227,15 +246,19 @@ Base.@kwdef struct HipImportanceBI <: BOSS.ModelFitter{BOSS.BIParams}
     samples::Int
 end
 function estimate_parameters(f::HipImportanceBI, problem::BOSS.BossProblem, options::BOSS.BossOptions)
-    all = estimate_parameters(HipBatchedMAP(samples = f.candidates), problem, options; return_all = true)
-    ll = Float64[p.loglike for p in all]; w = exp.(ll .- maximum(ll)); w ./= sum(w)
-    idx = [findfirst(>=(rand()), cumsum(w)) for _ in 1:f.samples]
-    return BOSS.BIParams(samples = [all[something(i, length(all))].params for i in idx])
+    m = problem.model::Union{HipGaussianProcess, HipSemiparametric}
+    sampler = BOSS.params_sampler(m, problem.data)
+    ps = [sampler() for _ in 1:f.candidates]                           # proposal = the prior ...
+    ll = batched_data_loglike(m, problem.data, ps)                     # ... so the importance weight is the DATA likelihood alone
+    w = exp.(ll .- maximum(ll)); w ./= sum(w); cw = cumsum(w)          # (weighting with likelihood × prior would target likelihood × prior²)
+    idx = [findfirst(>=(rand()), cw) for _ in 1:f.samples]
+    return BOSS.BIParams(samples = [ps[something(i, length(ps))] for i in idx])
 end
 
 # ---------------------------------------------------------------- ModelFitter (SamplingMAP semantics, batched)
 Base.@kwdef struct HipBatchedMAP <: BOSS.ModelFitter{BOSS.MAPParams}
     samples::Int
+    devices::Int = 1              # > 1: the samples split over that many GPUs inside the library (boss_multi_loglike_batch)
 end
 gp_kernel(m::HipGaussianProcess) = m.gp.kernel
 gp_kernel(m::HipSemiparametric) = m.sp.nonparametric.kernel
@@ -249,33 +272,54 @@ function batch_means(m::HipSemiparametric, ps, X, i)                            
     end
     return F, size(X, 2)
 end
+"Data log-likelihood of every parameter set of `ps` (summed over the outputs): one batched device call per output; -Inf where not PD."
+function batched_data_loglike(m::Union{HipGaussianProcess, HipSemiparametric}, data::BOSS.ExperimentData, ps::AbstractVector;
+                              devices::Int = 1)
+    X = Matrix{Float64}(data.X); S = length(ps); ll = zeros(S); k = gp_kernel(m)
+    for i in 1:size(data.Y, 1)
+        λ = Matrix{Float64}(reduce(hcat, (p.λ[:, i] for p in ps))); lli = zeros(S); st = zeros(Cint, S)
+        mv, stride = batch_means(m, ps, X, i)
+        α = Float64[p.α[i] for p in ps]; σ = Float64[p.σ[i] for p in ps]; y = Vector{Float64}(data.Y[i, :])
+        if devices > 1                                                  # the S sets split over the GPUs of the node (no collective)
+            n = Ref{Cint}(); check(ccall((:boss_init, lib), Cint, (Ref{Cint},), n)); @assert devices <= n[]
+            check(ccall((:boss_multi_loglike_batch, lib), Cint,
+                (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint,
+                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
+                devices, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, y, mv, stride, discrete_flags(k), S, λ, α, σ, lli, st))
+        else
+            check(ccall((:boss_gp_loglike_batch, lib), Cint,
+                (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint,
+                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
+                m.device, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, y, mv, stride, discrete_flags(k), S, λ, α, σ, lli, st))
+        end
+        ll .+= lli
+    end
+    return ll
+end
 function estimate_parameters(f::HipBatchedMAP, problem::BOSS.BossProblem, options::BOSS.BossOptions; return_all=false)
     m = problem.model::Union{HipGaussianProcess, HipSemiparametric}; data = problem.data
     sampler = BOSS.params_sampler(m, data); prior = params_loglike(m)
     ps = [sampler() for _ in 1:f.samples]
-    X = Matrix{Float64}(data.X); ll = zeros(f.samples); k = gp_kernel(m)
-    for i in 1:size(data.Y, 1)
-        λ = reduce(hcat, (p.λ[:, i] for p in ps)); lli = zeros(f.samples); st = zeros(Cint, f.samples)
-        mv, stride = batch_means(m, ps, X, i)
-        check(ccall((:boss_gp_loglike_batch, lib), Cint,
-            (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{UInt8}, Cint,
-             Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
-            m.device, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]),
-            mv, stride, discrete_flags(k), f.samples,
-            Matrix{Float64}(λ), Float64[p.α[i] for p in ps], Float64[p.σ[i] for p in ps], lli, st))
-        ll .+= lli
-    end
-    ll .+= prior.(ps)
+    ll = batched_data_loglike(m, data, ps; devices = f.devices) .+ prior.(ps)     # model_loglike = data + prior (src/surrogate_model.jl)
     return_all && return BOSS.MAPParams.(ps, ll)
     b = argmax(ll); return BOSS.MAPParams(ps[b], ll[b])
 end
 
-# ---------------------------------------------------------------- AcquisitionMaximizer (SamplingAM semantics, batched)
+# ---------------------------------------------------------------- AcquisitionMaximizer (SamplingAM / GridAM semantics, batched)
 Base.@kwdef struct HipBatchAM <: BOSS.AcquisitionMaximizer
-    x_prior
-    samples::Int
+    x_prior = nothing
+    samples::Int = 0
+    points::Union{Nothing, Matrix{Float64}} = nothing   # a FIXED candidate set (GridAM's grid, grid.jl:52-65) instead of `samples` draws
     max_attempts::Int = 200
-    devices::Int = 1              # > 1: candidates sharded over that many GPUs inside the library (boss_multi_acq_ei, RCCL)
+    devices::Int = 1              # > 1: sharded over that many GPUs inside the library (RCCL), along `shard`
+    shard::Symbol = :candidates   # :candidates (BASELINE config 3) | :outputs (config 4) | :samples (config 5)
+end
+"The candidate columns of one acquisition call (sampling.jl:43-46: draws from `x_prior` inside the domain; or the fixed grid)."
+function candidates(am::HipBatchAM, problem::BOSS.BossProblem)
+    isnothing(am.points) || return am.points
+    xs = BOSS._reduce_samples([BOSS._rand_in_domain(am.x_prior, problem.domain; am.max_attempts) for _ in 1:am.samples])
+    size(xs, 2) == 0 && @error "HipBatchAM: No samples were successfully drawn!\nCheck the `x_prior` and the `Domain`."
+    return Matrix{Float64}(xs)
 end
 "Prior means at the candidates in the layout boss_acq_ei wants: index p + P*(j + M*s) = a P×M×S array; C_NULL for zero means."
 function prior_means(posts::AbstractVector, xs::AbstractMatrix{Float64})
@@ -287,25 +331,27 @@ function prior_means(posts::AbstractVector, xs::AbstractMatrix{Float64})
     end
     return ms
 end
-function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions;
-                              posts = BOSS.model_posterior(problem), return_all::Bool = false)
+"What every acquisition entry point takes besides handles and candidates: (coefs, y_max, has_best, best, mask)."
+function ei_arguments(problem::BOSS.BossProblem, xs::AbstractMatrix{Float64})
     ei = problem.acquisition::BOSS.ExpectedImprovement{<:BOSS.LinFitness}
-    xs = BOSS._reduce_samples([BOSS._rand_in_domain(am.x_prior, problem.domain; am.max_attempts) for _ in 1:am.samples])
-    size(xs, 2) == 0 && @error "HipBatchAM: No samples were successfully drawn!\nCheck the `x_prior` and the `Domain`."
-    xs = Matrix{Float64}(xs)
-    posts isa AbstractVector || (posts = [posts])                          # BI: a vector of posteriors (src/posterior.jl:15-19)
-    P = BOSS.y_dim(problem); S = length(posts); M = size(xs, 2)
-    hs = Ptr{Cvoid}[posts[s].slices[p].h.h for p in 1:P, s in 1:S]         # P×S, column-major = gps[p + P*s]
     b = BOSS.best_so_far(problem, ei.fitness)
     mask = UInt8[BOSS.in_bounds(x, problem.domain.bounds) && BOSS.in_cons(x, problem.domain.cons) for x in eachcol(xs)]
     ymax = Float64[c for c in problem.y_max]                               # BOSS.Infinity converts to Inf (src/utils/inf.jl)
+    return Float64.(ei.fitness.coefs), ymax, isnothing(b) ? Cint(0) : Cint(1), Float64(something(b, 0.0)), ei.cons_safe ? mask : C_NULL
+end
+function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions;
+                              posts = BOSS.model_posterior(problem), return_all::Bool = false)
+    xs = candidates(am, problem)
+    posts isa AbstractVector || (posts = [posts])                          # BI: a vector of posteriors (src/posterior.jl:15-19)
+    P = BOSS.y_dim(problem); S = length(posts); M = size(xs, 2)
+    hs = Ptr{Cvoid}[posts[s].slices[p].h.h for p in 1:P, s in 1:S]         # P×S, column-major = gps[p + P*s]
+    coefs, ymax, hb, b, mask = ei_arguments(problem, xs)
     ms = prior_means(posts, xs)
     acq = return_all ? Vector{Float64}(undef, M) : C_NULL
     am_idx = Ref{Clong}(); mx = Ref{Cdouble}()
     GC.@preserve posts begin
         if am.devices > 1
-            # replicas of every posterior on devices 1..G-1 under the same hyper-parameters, then ONE sharded call
-            rc = multi_acq_ei(am.devices, problem, posts, xs, ms, ei, ymax, b, mask, acq, am_idx, mx)
+            rc = multi_acq_ei(am, problem, posts, xs, ms, coefs, ymax, hb, b, mask, acq, am_idx, mx)
         else
             cand = Ref{Ptr{Cvoid}}()
             check(ccall((:boss_cand_create, lib), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
@@ -313,8 +359,7 @@ function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options
             rc = ccall((:boss_acq_ei, lib), Cint,
                 (Cint, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
                  Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
-                P, S, hs, cand[], ms, Float64.(ei.fitness.coefs), ymax,
-                isnothing(b) ? 0 : 1, something(b, 0.0), ei.cons_safe ? mask : C_NULL, acq, am_idx, mx)
+                P, S, hs, cand[], ms, coefs, ymax, hb, b, mask, acq, am_idx, mx)
             ccall((:boss_cand_free, lib), Cvoid, (Ptr{Cvoid},), cand[])
         end
     end
@@ -322,19 +367,58 @@ function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options
     return_all && return xs, acq
     return xs[:, am_idx[] + 1], mx[]
 end
-"Candidates sharded over G GPUs from this one process (SURVEY §8e): boss_init, replicas via model_posterior_slice on every device."
-function multi_acq_ei(G::Int, problem, posts, xs, ms, ei, ymax, b, mask, acq, am_idx, mx)
-    n = Ref{Cint}(); check(ccall((:boss_init, lib), Cint, (Ref{Cint},), n)); @assert G <= n[]
+
+# ---- several GPUs from this one process (SURVEY §8e): the three sharding axes of the acquisition
+"G replicas of output slice i under hyper-parameters p: created on devices 0..G-1, factorised CONCURRENTLY (boss_multi_gp_update)."
+function slice_replicas(G::Int, m::HipGaussianProcess, p::HipGPParams, data::BOSS.ExperimentData, i::Int)
+    X = Matrix{Float64}(data.X); y = Vector{Float64}(data.Y[i, :]); k = m.gp.kernel
+    mu = BOSS.mean_getindex(m.gp.mean, i)
+    hs = map(0:G-1) do g
+        h = Ref{Ptr{Cvoid}}()
+        check(ccall((:boss_gp_create, lib), Cint, (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+              g, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, y, discrete_flags(k), h))
+        Handle(h[])
+    end
+    lp = Ref{Cdouble}()
+    GC.@preserve hs check(ccall((:boss_multi_gp_update, lib), Cint,
+        (Cint, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Ref{Cdouble}),
+        G, Ptr{Cvoid}[h.h for h in hs], Vector{Float64}(p.λ[:, i]), p.α[i], p.σ[i], mean_vals(mu, X), lp))
+    return [HipPosteriorSlice(h, mu) for h in hs]
+end
+function multi_acq_ei(am::HipBatchAM, problem, posts, xs, ms, coefs, ymax, hb, b, mask, acq, am_idx, mx)
+    G = am.devices; nd, _ = init_devices(); @assert G <= nd
     P = BOSS.y_dim(problem); S = length(posts); M = size(xs, 2)
+    m = problem.model::HipGaussianProcess
     params = BOSS.get_params(problem.params); params isa AbstractVector || (params = [params])
-    reps = [g == 0 ? posts : [BOSS.model_posterior(HipGaussianProcess(problem.model.gp, Cint(g)), prm, problem.data) for prm in params]
-            for g in 0:G-1]
-    hs = Ptr{Cvoid}[reps[g][s].slices[p].h.h for p in 1:P, s in 1:S, g in 1:G]      # gps[p + P*(s + S*g)]
-    GC.@preserve reps ccall((:boss_multi_acq_ei, lib), Cint,
-        (Cint, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
+    if am.shard == :candidates
+        # replicas of every posterior on all G devices (concurrent factorisations), the candidate columns split M/G, ONE 16-byte-per-rank
+        # all-gather for the arg-max; the shards stay resident for the call (boss_multi_cand_*: reuse them across calls on a fixed grid)
+        reps = [slice_replicas(G, m, params[s], problem.data, p) for p in 1:P, s in 1:S]         # [p, s][g]
+        hs = Ptr{Cvoid}[reps[p, s][g].h.h for p in 1:P, s in 1:S, g in 1:G]                      # gps[p + P*(s + S*g)]
+        mc = Ref{Ptr{Cvoid}}()
+        check(ccall((:boss_multi_cand_create, lib), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}), G, size(xs, 1), M, xs, mc))
+        rc = GC.@preserve reps ccall((:boss_multi_acq_ei_cand, lib), Cint,
+            (Cint, Cint, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
+             Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
+            G, P, S, hs, mc[], ms, coefs, ymax, hb, b, mask, acq, am_idx, mx)
+        ccall((:boss_multi_cand_free, lib), Cvoid, (Ptr{Cvoid},), mc[])
+        return rc
+    end
+    # :outputs — slice p lives on device (p-1) % G;  :samples — all outputs of sample s live on device (s-1) % G.  Each posterior is
+    # fitted where it lives; (μ, σ²) rows resp. partial acquisition sums travel in ONE all-reduce (host_multi.inc)
+    own(p, s) = am.shard == :outputs ? (p - 1) % G : (s - 1) % G
+    sl = [model_posterior_slice(HipGaussianProcess(m.gp, Cint(own(p, s))), params[s], problem.data, p) for p in 1:P, s in 1:S]
+    hs = Ptr{Cvoid}[sl[p, s].h.h for p in 1:P, s in 1:S]
+    if am.shard == :outputs
+        return GC.@preserve sl ccall((:boss_multi_acq_ei_outputs, lib), Cint,
+            (Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
+             Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
+            P, S, hs, M, xs, ms, coefs, ymax, hb, b, mask, acq, am_idx, mx)
+    end
+    return GC.@preserve sl ccall((:boss_multi_acq_ei_samples, lib), Cint,
+        (Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8},
          Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
-        G, P, S, hs, M, xs, ms, Float64.(ei.fitness.coefs), ymax, isnothing(b) ? 0 : 1, something(b, 0.0),
-        ei.cons_safe ? mask : C_NULL, acq, am_idx, mx)
+        P, S, hs, M, xs, ms, coefs, ymax, hb, b, mask, acq, am_idx, mx)
 end
 # ---------------------------------------------------------------- SequentialBatchAM on resident posteriors
 # batch.jl:26-38 rebuilds the posterior (an O(N^3) Cholesky) for every speculative point; here the
@@ -345,19 +429,67 @@ function append!(post::HipPosteriorSlice, x::AbstractVector{<:Real}, y::Real)
           post.h.h, 1, X, Float64[y], mean_vals(post.mean, X), lp))    # mean_new is required when the posterior has a prior mean
     return lp[]
 end
+"Observations currently in the handle (`size(data.X, 2)` after augment_dataset!, also after an append that failed part-way)."
+n_obs(post::HipPosteriorSlice) = (n = Ref{Cint}(); check(ccall((:boss_gp_n, lib), Cint, (Ptr{Cvoid}, Ref{Cint}), post.h.h, n)); Int(n[]))
+"Room for `extra` later appends without re-allocation; leaves the handle unfitted (follow with an update under the same parameters)."
+reserve!(post::HipPosteriorSlice, extra::Int) =
+    check(ccall((:boss_gp_reserve, lib), Cint, (Ptr{Cvoid}, Cint), post.h.h, n_obs(post) + extra))
+"New observations of the same inputs (a re-evaluated objective): y only, the points stay resident; follow with an update."
+set_y!(post::HipPosteriorSlice, y::AbstractVector{<:Real}) =
+    check(ccall((:boss_gp_set_y, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), post.h.h, Vector{Float64}(y)))
 Base.@kwdef struct HipSequentialBatchAM <: BOSS.AcquisitionMaximizer
     am::HipBatchAM
     batch_size::Int
 end
 function maximize_acquisition(sb::HipSequentialBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions)
     problem_ = deepcopy(problem); post = BOSS.model_posterior(problem_)
+    post isa AbstractVector && return sequential_untracked(sb, problem_, post, options)       # BI: appends to every sample's posterior
+    isnothing(sb.am.points) || sb.am.devices > 1 || return sequential_tracked(sb, problem_, post)
+    return sequential_untracked(sb, problem_, [post], options)
+end
+function sequential_untracked(sb, problem_, posts, options)
     X = reduce(hcat, map(1:sb.batch_size) do _
-        x, _ = maximize_acquisition(sb.am, problem_, options; posts = post)   # HipBatchAM with given handles
-        y = BOSS.mean(post, x)
+        x, _ = maximize_acquisition(sb.am, problem_, options; posts)          # HipBatchAM with given handles
+        y = sum(BOSS.mean(post, x) for post in posts) ./ length(posts)      # mean(post, x); BI: average_mean (src/posterior.jl:177-179)
         BOSS.augment_dataset!(problem_, x, y)
-        foreach(i -> append!(post.slices[i], x, y[i]), eachindex(y))
+        foreach(post -> foreach(i -> append!(post.slices[i], x, y[i]), eachindex(y)), posts)
         x
     end)
+    return X, nothing
+end
+"Fixed candidate set (`points`): the candidates' V = C.U' \\ K* slabs stay resident (boss_track_*) and every speculative observation
+extends them by ONE row — O(N·M) per selection instead of the O(N²M) re-solve (batch.jl:32-38)."
+function sequential_tracked(sb, problem_, post)
+    xs = sb.am.points; P = BOSS.y_dim(problem_); M = size(xs, 2)
+    cand = Ref{Ptr{Cvoid}}()
+    check(ccall((:boss_cand_create, lib), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}), problem_.model.device, size(xs, 1), M, xs, cand))
+    tracks = map(post.slices) do sl
+        t = Ref{Ptr{Cvoid}}()
+        check(ccall((:boss_track_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}), sl.h.h, cand[], mean_vals(sl.mean, xs), t))
+        t[]
+    end
+    X = try
+        reduce(hcat, map(1:sb.batch_size) do _
+            coefs, ymax, hb, b, mask = ei_arguments(problem_, xs)           # best_so_far moves with the speculative data
+            am_idx = Ref{Clong}(); mx = Ref{Cdouble}()
+            check(ccall((:boss_acq_ei_tracks, lib), Cint,
+                (Cint, Cint, Ptr{Ptr{Cvoid}}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8}, Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
+                P, 1, tracks, coefs, ymax, hb, b, mask, C_NULL, am_idx, mx))
+            x = xs[:, am_idx[] + 1]
+            y = map(tracks) do t                                           # ŷ = mean(post, x): read off the tracked state
+                μ = Ref{Cdouble}(); σ2 = Ref{Cdouble}()
+                check(ccall((:boss_track_moments, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}, Ref{Cdouble}), t, am_idx[], 1, μ, σ2))
+                μ[]
+            end
+            BOSS.augment_dataset!(problem_, x, y)
+            foreach(i -> append!(post.slices[i], x, y[i]), eachindex(y))
+            foreach(t -> check(ccall((:boss_track_sync, lib), Cint, (Ptr{Cvoid},), t)), tracks)   # one new row of V per track
+            x
+        end)
+    finally
+        foreach(t -> ccall((:boss_track_free, lib), Cvoid, (Ptr{Cvoid},), t), tracks)
+        ccall((:boss_cand_free, lib), Cvoid, (Ptr{Cvoid},), cand[])
+    end
     return X, nothing
 end
 # ---------------------------------------------------------------- analytic gradients (instead of ForwardDiff duals)
@@ -409,6 +541,112 @@ function loglike_and_grad_batch(m::HipGaussianProcess, data::BOSS.ExperimentData
         discrete_flags(m.gp.kernel), S, λ, α, σ, ll, g, st))
     return ll, g, st          # ll[s] = -Inf and g[:, s] = 0 where st[s] != 0 (not PD / invalid parameters)
 end
+# ---------------------------------------------------------------- OptimizationAM semantics on analytic device gradients
+"""
+`HipGradientAM` — OptimizationAM semantics (src/acquisition_maximizers/optimization.jl:13-118): multistart LOCAL optimisation of
+the acquisition from `multistart` starts inside the domain, the best local optimum wins (`optimize_multistart`,
+src/utils/optim_multistart.jl).  The reference differentiates the acquisition with ForwardDiff (:36) one start at a time; here
+the gradient is analytic and evaluated on the device for ALL starts in one call per iteration (`boss_acq_ei_grad`): projected
+gradient ascent with a per-start step and backtracking.  Discrete dimensions are rounded (gradient 0); `cons` is honoured through
+make_safe (acq = 0 outside) and a final in-domain filter.
+"""
+Base.@kwdef struct HipGradientAM <: BOSS.AcquisitionMaximizer
+    multistart::Union{Int, Matrix{Float64}} = 200        # number of starts, or the starts as columns (set_starts, optimization.jl:43-52)
+    iters::Int = 30
+end
+BOSS.set_starts(am::HipGradientAM, starts::AbstractMatrix{<:Real}) = HipGradientAM(Matrix{Float64}(starts), am.iters)
+function maximize_acquisition(am::HipGradientAM, problem::BOSS.BossProblem, options::BOSS.BossOptions;
+                              posts = BOSS.model_posterior(problem))
+    dom = problem.domain; lb, ub = Float64.(dom.bounds[1]), Float64.(dom.bounds[2])
+    X = Matrix{Float64}(BOSS.get_starts(am.multistart, dom))              # LHC starts (optimization.jl:78-88) or the given ones
+    posts isa AbstractVector || (posts = [posts])
+    value_and_grad(Z) = begin                                              # BI: the sample mean of acquisition and gradient (:87-90)
+        vg = [acq_value_and_grad(problem, post, Z) for post in posts]
+        sum(first.(vg)) ./ length(posts), sum(last.(vg)) ./ length(posts)
+    end
+    span = map((l, u) -> isfinite(u - l) ? u - l : 1.0, lb, ub); cont = .!dom.discrete
+    f, g = value_and_grad(X); step = fill(0.05, size(X, 2))                # step relative to the box, per start
+    for _ in 1:am.iters
+        gn = g .* span; gn[.!cont, :] .= 0.0
+        nrm = max.(sqrt.(vec(sum(abs2, gn; dims = 1))), 1e-300)
+        Xn = clamp.(X .+ (gn ./ nrm') .* span .* step', lb, ub)
+        fn, gnw = value_and_grad(Xn)
+        better = fn .> f
+        X[:, better] .= Xn[:, better]; f[better] .= fn[better]; g[:, better] .= gnw[:, better]
+        step .= ifelse.(better, min.(step .* 1.5, 0.5), step .* 0.4)
+        all(<(1e-7), step) && break
+    end
+    X .= BOSS.cond_func(round).(X, dom.discrete)                           # assure discrete dims (optimization.jl:115)
+    ok = [BOSS.in_domain(x, dom) for x in eachcol(X)]
+    f, _ = value_and_grad(X); f[.!ok] .= -Inf
+    j = argmax(f); return X[:, j], f[j]
+end
+
+# ---------------------------------------------------------------- OptimizationMAP semantics on analytic device gradients
+"""
+`HipGradientMAP` — OptimizationMAP semantics (src/model_fitters/optimization.jl:13-164): multistart local maximisation of the
+log-posterior `loglike(data | θ) + logprior(θ)` over the GP hyper-parameters, the best local optimum wins.  The reference hands
+the objective to an Optimization.jl algorithm with automatic differentiation (:146-164); here the starts advance in lockstep and
+every round is ONE device call per output — `boss_gp_loglike_grad_batch`: values and analytic gradients of all trial points —
+and the ascent runs in log-parameter space (positive parameters; the reference's bijector maps them the same way).  Parameters
+with a Dirac prior stay fixed (src/models/utils/dirac.jl:36-77); the priors' gradient comes from ForwardDiff (a few scalars).
+"""
+Base.@kwdef struct HipGradientMAP <: BOSS.ModelFitter{BOSS.MAPParams}
+    multistart::Union{Int, Vector{<:HipGPParams}} = 8
+    iters::Int = 40
+    step0::Float64 = 0.3
+end
+BOSS.set_starts(f::HipGradientMAP, starts::AbstractVector{<:HipGPParams}) = HipGradientMAP(collect(starts), f.iters, f.step0)
+flat(p::HipGPParams) = vcat(vec(p.λ), p.α, p.σ)
+unflat(p::HipGPParams, v::AbstractVector) = (n = length(p.λ); P = length(p.α);
+    HipGPParams(reshape(v[1:n], size(p.λ)), v[n+1:n+P], v[n+P+1:n+2P]))
+"log-posterior and its gradient w.r.t. flat(p) = [vec(λ); α; σ] for every parameter set: one batched device call per output."
+function objective_batch(m::HipGaussianProcess, data::BOSS.ExperimentData, ps::AbstractVector{<:HipGPParams})
+    prior = params_loglike(m); S = length(ps); d, P = size(ps[1].λ)
+    f = Float64[prior(p) for p in ps]
+    G = [BOSS.ForwardDiff.gradient(v -> prior(unflat(p, v)), flat(p)) for p in ps]      # the priors: host scalars
+    for i in 1:P
+        λ = Matrix{Float64}(reduce(hcat, (p.λ[:, i] for p in ps)))
+        ll, g, st = loglike_and_grad_batch(m, data, i, λ, Float64[p.α[i] for p in ps], Float64[p.σ[i] for p in ps])
+        for s in 1:S
+            f[s] += st[s] == 0 ? ll[s] : -Inf
+            G[s][(i-1)*d+1:i*d] .+= g[1:d, s]; G[s][d*P+i] += g[d+1, s]; G[s][d*P+P+i] += g[d+2, s]
+        end
+    end
+    return f, G
+end
+function estimate_parameters(fit::HipGradientMAP, problem::BOSS.BossProblem, options::BOSS.BossOptions; return_all::Bool = false)
+    m = problem.model::HipGaussianProcess; data = problem.data
+    sampler = BOSS.params_sampler(m, data)
+    ps = fit.multistart isa Int ? [sampler() for _ in 1:fit.multistart] : copy(fit.multistart)
+    free = .!first(BOSS.create_dirac_mask(BOSS.param_priors(m)))            # over flat(p): Dirac-prior parameters do not move
+    f, G = objective_batch(m, data, ps)
+    step = fill(fit.step0, length(ps)); its = zeros(Int, length(ps)); alive = isfinite.(f) .& (fit.iters > 0)
+    while any(alive)
+        idx = Int[]; trial = eltype(ps)[]
+        for k in findall(alive)
+            v = flat(ps[k]); dir = ifelse.(free, v .* G[k], 0.0)            # ∂f/∂log θ = θ ∂f/∂θ
+            nrm = sqrt(sum(abs2, dir))
+            nrm < 1e-10 && (alive[k] = false; continue)
+            push!(idx, k); push!(trial, unflat(ps[k], v .* exp.(step[k] .* dir ./ nrm)))
+        end
+        isempty(idx) && break
+        fq, Gq = objective_batch(m, data, trial)                            # ALL trial points of the round in one call per output
+        for (j, k) in enumerate(idx)
+            if fq[j] > f[k]
+                ps[k], f[k], G[k] = trial[j], fq[j], Gq[j]
+                step[k] = min(step[k] * 1.6, 2.0); its[k] += 1
+                its[k] >= fit.iters && (alive[k] = false)
+            else
+                step[k] *= 0.4
+                step[k] <= 1e-6 && (alive[k] = false)
+            end
+        end
+    end
+    return_all && return BOSS.MAPParams.(ps, f)
+    b = argmax(f); return BOSS.MAPParams(ps[b], f[b])
+end
+
 # ---------------------------------------------------------------- GradientGaussianProcess (values + gradients)
 # BOSS.GradientGaussianProcess with the n(1+d) augmented system on the device; data::BOSS.GradientData.
 struct HipGradientGaussianProcess{G<:BOSS.GradientGaussianProcess} <: BOSS.SurrogateModel
@@ -466,4 +704,34 @@ function mean_and_var(p::HipNonstationaryPosterior, X::AbstractMatrix{<:Real})
         p.post.h.h, M, Xs, reduce(hcat, p.f_λ.(eachcol(Xr))), Float64.(p.f_α.(eachcol(Xr))), mean_vals(p.post.mean, Xs), μ, σ2, bad))
     return μ, σ2
 end
+# ---------------------------------------------------------------- moments with gradients, moments-only acquisition
+"mean_and_var(post, X) with their analytic gradients w.r.t. the columns of X: (μ, σ², ∂μ/∂x (d×M), ∂σ²/∂x (d×M))."
+function mean_and_var_grad(post::HipPosteriorSlice, X::AbstractMatrix{<:Real}; mean_grad = C_NULL)
+    Xs = Matrix{Float64}(X); d, M = size(Xs)
+    μ = Vector{Float64}(undef, M); σ2 = similar(μ); dμ = Matrix{Float64}(undef, d, M); dσ2 = similar(dμ); bad = Ref{Clong}(-1)
+    GC.@preserve post check(ccall((:boss_gp_predict_grad, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}),
+        post.h.h, M, Xs, mean_vals(post.mean, Xs), mean_grad, μ, σ2, dμ, dσ2, bad))
+    return μ, σ2, dμ, dσ2
+end
+"EI × feasibility and arg-max from moments the caller already holds (e.g. of a HipNonstationaryPosterior): mu, var are M×P×S arrays."
+function acq_from_moments(problem::BOSS.BossProblem, xs::AbstractMatrix{Float64}, mu::Array{Float64, 3}, var::Array{Float64, 3}; device = 0)
+    M, P, S = size(mu); coefs, ymax, hb, b, mask = ei_arguments(problem, xs)
+    acq = Vector{Float64}(undef, M); am_idx = Ref{Clong}(); mx = Ref{Cdouble}()
+    check(ccall((:boss_acq_ei_moments, lib), Cint,
+        (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{UInt8}, Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}),
+        device, P, S, M, mu, var, coefs, ymax, hb, b, mask, acq, am_idx, mx))
+    return acq, am_idx[] + 1, mx[]
+end
+
+# ---------------------------------------------------------------- entry points of include/bosship.h this glue does not call
+# (tests/test_abi_and_host.py checks that every exported symbol is either bound above or listed here with its reason)
+# not bound: boss_set_stream — runs the library on a caller's HIP stream (torch / AMDGPU.jl interop); BOSS.jl itself owns no stream
+# not bound: boss_device_sync — drains that stream; every entry point used above returns synchronised results
+# not bound: boss_gp_get_factor — test introspection (L and z of a fitted handle); no BOSS.jl API asks for the factor
+# not bound: boss_bench_mfma_f64 — measurement helper of bench.py (fp64 MFMA issue-rate probe)
+# not bound: boss_prof_enable — measurement helper of bench.py (per-kernel-class HIP-event timers)
+# not bound: boss_prof_reset — measurement helper of bench.py
+# not bound: boss_prof_get — measurement helper of bench.py
+# not bound: boss_multi_acq_ei — superseded here by boss_multi_cand_create + boss_multi_acq_ei_cand (same exchange, candidate shards uploaded once)
 end # module

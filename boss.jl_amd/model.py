@@ -156,6 +156,32 @@ class HipGaussianProcess:
     def model_posterior(self, params, data: ExperimentData, reserve: int = 0):
         """model_posterior (src/posterior.jl:8-19,38-41): a vector of params broadcasts (BI samples)."""
         if isinstance(params, (list, tuple)):
+            if len(params) > 1 and reserve == 0:
+                # the S samples of a BI fit: per output ONE batched factorisation (boss_gp_fit_batch) — X and y uploaded once,
+                # the S posteriors resident as members of one set.  A sample whose matrix is not positive definite raises, as
+                # the reference's cholesky would inside the broadcast (src/posterior.jl:15-19)
+                P, S = data.Y.shape[0], len(params)
+                per_out = []
+                for i in range(P):
+                    means = [self.mean_values(data.X, p, i) for p in params]
+                    mX = None if all(m is None for m in means) else np.stack([np.zeros(data.X.shape[1]) if m is None else np.asarray(m, float)
+                                                                              for m in means])
+                    gps, _, st = api.fit_batch(data.X, data.Y[i], self.kernel, np.stack([p.lengthscales[:, i] for p in params], axis=1),
+                                               [p.amplitudes[i] for p in params], [p.noise_std[i] for p in params], mX, self.discrete,
+                                               self.device)
+                    if np.any(st != 0):
+                        for g in gps:
+                            g.close()
+                        for row in per_out:
+                            for g in row:
+                                g.close()
+                        bad = int(np.flatnonzero(st)[0])
+                        if st[bad] == api.BOSS_E_NOT_PD:
+                            raise api.PosDefException(api.BOSS_E_NOT_PD, f"sample {bad}, output {i}: matrix is not positive definite")
+                        raise api.BossError(int(st[bad]), f"sample {bad}, output {i}: invalid hyper-parameters")
+                    per_out.append(gps)
+                return [HipGaussianProcessPosterior([HipGaussianProcessPosteriorSlice(self, params[s], i, per_out[i][s]) for i in range(P)])
+                        for s in range(S)]
             return [self.model_posterior(p, data, reserve) for p in params]
         return HipGaussianProcessPosterior([self.model_posterior_slice(params, data, i, reserve)
                                             for i in range(data.Y.shape[0])])

@@ -193,6 +193,18 @@ int boss_gp_loglike_grad_batch(int device, int kernel, int d, int N, const doubl
                                const double* mean_X, int mean_stride, const unsigned char* discrete,
                                int S, const double* lengthscales, const double* amplitudes,
                                const double* noise_stds, double* ll_out, double* grad_out, int* status_out);
+/* S RESIDENT posteriors of one output slice out of ONE batched factorisation.
+ * Replaces: the broadcast `model_posterior.(Ref(model), params, Ref(data))` over the S parameter samples of a Bayesian-inference
+ * fit (src/posterior.jl:15-19; samples from ext/TuringExt.jl:88-107), i.e. S calls of posterior_gp (gaussian_process.jl:199-211)
+ * on the same (X, y) slice.  Arguments as boss_gp_loglike_batch; X and y are uploaded once and shared by the S members.
+ *   out S handles — ordinary boss_gp_t (predict, acquisition, gradients, update, append, free): each is freed with boss_gp_free;
+ *       the shared device storage goes with the last one.  A member whose status is not BOSS_OK is returned unfitted.
+ *   logpdf_out S log marginal likelihoods (-Inf where not PD) or NULL, status_out S (BOSS_OK / BOSS_E_NOT_PD / BOSS_E_INVALID) or NULL.
+ * boss_acq_ei walks S > 1 equally shaped posteriors of an output in one prediction launch (grid = candidate tiles × samples). */
+int boss_gp_fit_batch(int device, int kernel, int d, int N, const double* X, const double* y,
+                      const double* mean_X, int mean_stride, const unsigned char* discrete,
+                      int S, const double* lengthscales, const double* amplitudes,
+                      const double* noise_stds, boss_gp_t** out, double* logpdf_out, int* status_out);
 
 /* ---- prediction -------------------------------------------------------------------------
  * Replaces: mean_and_var(post, X::Matrix) (gaussian_process.jl:174-178) =

@@ -189,8 +189,29 @@ def test_integration_doc_shows_the_shipped_julia_glue():
     syms = set(header_symbols())
     called = set(re.findall(r"\(:(boss_[a-z0-9_]+), lib\)", jl))
     assert called and called <= syms, called - syms
-    for must in ("boss_gp_fit", "boss_gp_update", "boss_gp_predict", "boss_acq_ei", "boss_multi_acq_ei", "boss_init", "boss_gp_loglike_batch"):
+    for must in ("boss_gp_fit", "boss_gp_update", "boss_gp_predict", "boss_acq_ei", "boss_multi_acq_ei_cand", "boss_init", "boss_gp_loglike_batch",
+                 "boss_gp_fit_batch", "boss_multi_acq_ei_outputs", "boss_multi_acq_ei_samples", "boss_multi_loglike_batch", "boss_multi_gp_update",
+                 "boss_track_create", "boss_acq_ei_tracks", "boss_acq_ei_grad", "boss_gp_loglike_grad_batch"):
         assert must in called, must
+    # EVERY entry point of the header is either bound by the glue or listed in it with the reason why not
+    listed = dict(re.findall(r"# not bound: (boss_[a-z0-9_]+) — (.+)", jl))
+    assert not (set(listed) & called), set(listed) & called
+    missing = syms - called - set(listed)
+    assert not missing, f"exported by include/bosship.h but neither bound in BOSSHip.jl nor listed as '# not bound: <symbol> — <reason>': {sorted(missing)}"
+    assert set(listed) <= syms and all(len(r.strip()) >= 10 for r in listed.values())
+    # the plugin types a BOSS.jl user switches to: the sampling trio AND the gradient-based pair (OptimizationAM / OptimizationMAP
+    # semantics, /root/reference/src/acquisition_maximizers/optimization.jl:89-118, src/model_fitters/optimization.jl:146-164)
+    for typ, sup in (("HipBatchAM", "BOSS.AcquisitionMaximizer"), ("HipSequentialBatchAM", "BOSS.AcquisitionMaximizer"),
+                     ("HipGradientAM", "BOSS.AcquisitionMaximizer"), ("HipBatchedMAP", r"BOSS.ModelFitter\{BOSS.MAPParams\}"),
+                     ("HipGradientMAP", r"BOSS.ModelFitter\{BOSS.MAPParams\}"), ("HipImportanceBI", r"BOSS.ModelFitter\{BOSS.BIParams\}")):
+        assert re.search(r"struct %s\b[^\n]*<: %s" % (typ, sup), jl), typ
+    for fn in ("maximize_acquisition(am::HipGradientAM", "estimate_parameters(fit::HipGradientMAP", "maximize_acquisition(sb::HipSequentialBatchAM",
+               "estimate_parameters(f::HipImportanceBI", "estimate_parameters(f::HipBatchedMAP"):
+        assert fn in jl, fn
+    # importance resampling from the prior weights with the DATA likelihood alone (likelihood × prior would target likelihood × prior²)
+    bi = jl[jl.index("function estimate_parameters(f::HipImportanceBI"):]
+    bi = bi[:bi.index("\nend") + 4]
+    assert "batched_data_loglike" in bi and "prior" not in bi.replace("the prior", "").replace("× prior", "")
     # every method of the model API (/root/reference/src/types/surrogate_model.jl:19-73) is defined for BOTH device models:
     # the plain GP (BASELINE configs 1-3, 5) and the semiparametric model (config 4), each with a parameter type of its own
     for model, params in (("HipGaussianProcess", "HipGPParams"), ("HipSemiparametric", "HipSemiparametricParams")):
@@ -206,6 +227,8 @@ def test_integration_doc_shows_the_shipped_julia_glue():
     # the parametric mean reaches the device as mean vectors (semiparametric.jl:79-92), the BI flow as P×S handles (posterior.jl:15-19)
     assert "BOSS.add_mean(m.sp.nonparametric, m.sp.parametric(θ))" in jl and "batch_means(m::HipSemiparametric" in jl
     assert "BOSS.model_posterior(m::HipGaussianProcess, ps::AbstractVector{<:HipGPParams}" in jl and "BOSS.BIParams(samples" in jl
+    mpb = jl[jl.index("function model_posteriors_batched"):]
+    assert ":boss_gp_fit_batch" in mpb[:mpb.index("\nend")] and ":boss_gp_fit," not in mpb[:mpb.index("\nend")]   # ONE batched call per output, not S fits
     # every ccall passes as many arguments as its type tuple declares
     for m in re.finditer(r"ccall\(\(:(boss_[a-z0-9_]+), lib\), (\w+),\s*\(([^)]*)\)", jl, re.S):
         name, types = m.group(1), [t for t in m.group(3).replace("\n", " ").split(",") if t.strip()]
