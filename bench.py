@@ -43,6 +43,12 @@ KERNEL = "matern52"
 MAX_PROCS_PER_GPU = 6                 # the GPU box's process guard
 
 
+def note(msg):
+    """progress on stderr (rank 0): a long run must not look hung to whoever watches it"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def problem(seed):
     """SURVEY §8d config 2/3 inputs."""
     rng = np.random.default_rng(seed)
@@ -413,7 +419,9 @@ def main():
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
 
+    note("weak record: posterior update + 8192-candidate acquisition per step")
     elapsed, t_upd, t_acq = timed(step, args.steps, args.warmup)
+    note(f"  {args.steps * 1e3 / 1e3 / t_upd * world:.0f} updates/s, {elapsed / args.steps * 1e3:.3f} ms per step; strong record")
 
     # ------------------------------------------------------------------ strong: one posterior replicated, candidates M/G
     Xr, yr, Xsr = problem(1)                      # the same problem on every rank
@@ -448,6 +456,7 @@ def main():
 
     # ---- per-kernel HIP-event timing of the dominant kernels (separate pass, events on the library's stream)
     roof = roof_potrf = None
+    note("per-kernel event timing")
     if rank == 0:
         # (a) the dominant kernel inside the UNSERIALISED step: the update runs as always (resident chain, side stream), the event
         # pair is switched on for the acquisition call alone — two hipEventRecord around predict_kernel on the library's stream
@@ -495,6 +504,7 @@ def main():
 
     # ---- latency distribution of the posterior update (the resident chain's tail latency): 240 back-to-back updates
     upd_dist = None
+    note("update latency distribution")
     if rank == 0:
         ts = []
         for i in range(240):
@@ -509,6 +519,7 @@ def main():
     # ---- SURVEY §8f rows built beyond the headline path (rank 0, N=1 only; a fraction of a second)
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
+        note("next rows (gradients, appends, small sizes, gradient observations)")
         gp.update(lam, 1.0, 0.05)
         t0 = time.perf_counter()
         for _ in range(3):
@@ -591,6 +602,7 @@ def main():
     # ---- what DESIGN.md claims beyond the single-matrix chain, in the driver's own record (rank 0; N=1 only for the device work)
     batched = acq_by_m = None
     if rank == 0 and world == 1 and not args.no_extras:
+        note("batched updates, config 5, acquisition by call size")
         batched = {}
         rs = np.random.default_rng(4)
         for S in (8, 32):                                              # boss_gp_loglike_batch at N=4096: S hyper-parameter sets per call
@@ -618,6 +630,7 @@ def main():
         batched["config5_512xN1024"] = {"factorisations_per_sec": S5 / dt, "ms_per_call": dt * 1e3, "tflops": S5 * flops_update(N5, D) / dt / 1e12,
                                         "frac_of_fp64_mfma_peak": S5 * flops_update(N5, D) / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                         "all_positive_definite": bool((st5 == 0).all())}
+        note("  config 5 end to end (512 resident posteriors)")
         # BASELINE configs[4] end to end: the 512 posteriors RESIDENT out of one batched factorisation (boss_gp_fit_batch), then the
         # acquisition averaged over all of them at 8192 candidates (one prediction launch over candidate tiles × samples)
         t0 = time.perf_counter()
@@ -673,6 +686,7 @@ def main():
     # ---- configs[2] through the one-process multi-GPU entry points (a fresh child process: this one stays alive and idle meanwhile)
     inproc = None
     if rank == 0 and not args.no_extras:
+        note("one-process multi-device entry points (child process)")
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inproc-child", str(world), "--steps", str(args.steps),
@@ -683,6 +697,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("CPU baseline (oracle on the host cores)")
         cpu = cpu_baseline(X, y, Xs, lam)
 
     if rank == 0:

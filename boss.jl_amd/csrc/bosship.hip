@@ -89,7 +89,8 @@ struct Ctx {
     // the resident panel chain (chain.hpp): its own stream, the base of its sequence numbers, and whether it may be used at all
     // (it needs kernels of different streams to run at the same time: off wherever launches are known to be serialised)
     hipStream_t chain_stream = nullptr, strip_stream = nullptr;
-    unsigned long long chain_seq = 0, crit_seq = 0;
+    unsigned long long chain_seq = 0, crit_seq = 0, near_seq = 0;
+    int bulk_wgs = 0;                           // workgroups of the resident trailing update: one per CU, the chain's and the strips' CUs (and a few more) left free
     bool chain_ok = false;
     bool test_drop_chain = false;              // BOSS_TEST_DROP_CHAIN=1: the chain kernel is never launched (exercises the fallback)
     unsigned long long acq_seq = 0;            // sequence number of the arg-max result block (boss_acq_ei polls it)
@@ -196,6 +197,14 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_strips_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STRIPS_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_bulk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BULK_LDS_BYTES));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 0;
+        static const int spare = getenv("BOSS_BULK_SPARE_CUS") ? atoi(getenv("BOSS_BULK_SPARE_CUS")) : 6;
+        c->bulk_wgs = std::max(0, cus - 2 - 8 - spare);      // every one of them must be resident at the same time: never more than the CUs that can be free
+        if (c->bulk_wgs < 32) c->bulk_wgs = 0;
+    }
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_llgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LLG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
