@@ -525,6 +525,7 @@ def main():
         for _ in range(3):
             gp.predict_grad(Xs)
         t_grad = (time.perf_counter() - t0) / 3
+        note("  appends")
         rng = np.random.default_rng(7)
         g2 = api.GP(X, y, KERNEL, device=dev)
         g2.update(lam, 1.0, 0.05)
@@ -541,6 +542,7 @@ def main():
             ts.append(time.perf_counter() - t0)
         t_app1 = float(np.median(ts))
         g2.close()
+        note("  likelihood gradients, single-candidate predictions")
         gp.update(lam, 1.0, 0.05)
         gp.loglike_grad()
         t0 = time.perf_counter()
@@ -562,6 +564,7 @@ def main():
                   "block_cholesky_append_ms": t_app * 1e3, "rank_one_append_ms": t_app1 * 1e3,
                   "append_vs_refactorisation": (t_upd / args.steps) / t_app1,
                   "posterior_gradient_evals_per_sec": M_CAND / t_grad, "ms_gradient_batch": t_grad * 1e3}
+        note("  N = 20")
         # BASELINE.json configs[0] regime (examples/example.jl: N≈20, d=1): one posterior update
         rs = np.random.default_rng(555)
         x1 = rs.uniform(0, 20, (1, 20))
@@ -581,6 +584,7 @@ def main():
         gs.close()
         # gradient observations (GradientGaussianProcess, §8f4): the n(1+d) = 36 864-row augmented system of the same
         # N=4096, d=8 data — 10.9 GB resident, 1.67e13 flops per update
+        note("  gradient observations (36 864 rows)")
         w = np.linspace(1.0, 2.0, D)[:, None]
         yg = np.sin(2 * np.pi * w * X).sum(0) / np.sqrt(D)
         dYg = 2 * np.pi * w * np.cos(2 * np.pi * w * X) / np.sqrt(D)

@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbosship.so")
+LIB_PATH = os.environ.get("BOSS_LIB_PATH") or os.path.join(_HERE, "libbosship.so")      # (BOSS_LIB_PATH: A/B timing of another build, tools/)
 
 BOSS_OK, BOSS_E_INVALID, BOSS_E_NO_DEVICE, BOSS_E_NOT_PD, BOSS_E_NEG_VAR, BOSS_E_NOT_FITTED, BOSS_E_ALLOC = range(7)
 KERNELS = {"matern32": 0, "matern52": 1, "sqexp": 2}
@@ -126,6 +126,8 @@ def load_library(path: Optional[str] = None):
             "(bosship has no CPU fallback)")
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("BOSS_LIB_PATH") and not hasattr(lib, name):
+            continue                                   # (an older build under A/B timing lacks the newer entry points)
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -9,12 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <limits>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gp_kernels.hpp"
@@ -89,7 +91,8 @@ struct Ctx {
     // the resident panel chain (chain.hpp): its own stream, the base of its sequence numbers, and whether it may be used at all
     // (it needs kernels of different streams to run at the same time: off wherever launches are known to be serialised)
     hipStream_t chain_stream = nullptr, strip_stream = nullptr;
-    unsigned long long chain_seq = 0, crit_seq = 0, near_seq = 0;
+    unsigned long long chain_seq = 0, crit_seq = 0, near_seq = 0, up_seq = 0;
+    int n_cus = 256;
     int bulk_wgs = 0;                           // workgroups of the resident trailing update: one per CU, the chain's and the strips' CUs (and a few more) left free
     bool chain_ok = false;
     bool test_drop_chain = false;              // BOSS_TEST_DROP_CHAIN=1: the chain kernel is never launched (exercises the fallback)
@@ -168,8 +171,35 @@ static int ctx_init(Ctx* c) {
                                      getenv("ROCPROF_COUNTER_GROUPS") || set_nonzero("ROCPROF_ADVANCED_THREAD_TRACE") ||
                                      getenv("ROCPROF_ATT_PARAM_SERIALIZE_ALL") || getenv("ROCP_METRICS") || set_nonzero("AMD_SERIALIZE_KERNEL");
         if (!gate_off) {
-            HIPCHK(hipMalloc((void**)&c->sig_panel, SIG_WORDS * sizeof(unsigned long long)));
-            HIPCHK(hipMemset(c->sig_panel, 0, SIG_WORDS * sizeof(unsigned long long)));
+            if (set_nonzero("BOSS_DEBUG_WATCH")) {
+                // diagnostics only: the signal words in mapped host memory (slow to poll, but a host thread can watch them without a
+                // single HIP call — whatever the runtime or the device is stuck in) and a watcher thread that prints them when they move
+                unsigned long long* hp = nullptr;
+                HIPCHK(hipHostMalloc((void**)&hp, SIG_WORDS * sizeof(unsigned long long), hipHostMallocMapped));
+                std::memset(hp, 0, SIG_WORDS * sizeof(unsigned long long));
+                HIPCHK(hipHostGetDevicePointer((void**)&c->sig_panel, hp, 0));
+                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(boss::g_dbg), &c->sig_panel, sizeof(void*)));
+                std::thread([hp]() {
+                    unsigned long long last[SIG_WORDS] = {0};
+                    for (;;) {
+                        std::this_thread::sleep_for(std::chrono::milliseconds(500));
+                        unsigned long long now[SIG_WORDS];
+                        for (int i = 0; i < SIG_WORDS; ++i) now[i] = ((volatile unsigned long long*)hp)[i];
+                        if (std::memcmp(now, last, sizeof now) == 0) continue;
+                        std::memcpy(last, now, sizeof now);
+                        std::fprintf(stderr, "[bosship watch] up %llu wdone %llu panel %llu crit %llu | gate %llu near %llu bulk %llu | fdone %llu nearcnt %llu | strips",
+                                     now[SIGW_UP], now[SIGW_WDONE], now[SIGW_PANEL], now[SIGW_CRIT], now[SIGW_GATE], now[SIGW_NEAR], now[SIGW_BULK], now[SIGW_FDONE],
+                                     now[SIGW_NEARCNT]);
+                        for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %llu", now[SIGW_PROG + SIGW_PROG_STRIDE * q]);
+                        std::fprintf(stderr, " | give-ups: first %llu n %llu last %llu; waits ended by mark %llu, by clock %llu", now[SIGW_DBG], now[SIGW_DBG + 1],
+                                     now[SIGW_DBG + 2], now[SIGW_DBG + 4], now[SIGW_DBG + 5]);
+                        std::fprintf(stderr, "\n");
+                    }
+                }).detach();
+            } else {
+                HIPCHK(hipMalloc((void**)&c->sig_panel, SIG_WORDS * sizeof(unsigned long long)));
+                HIPCHK(hipMemset(c->sig_panel, 0, SIG_WORDS * sizeof(unsigned long long)));
+            }
         }
         // (gates are enqueued behind their producers and survive launches that execute one at a time; the resident chain cannot)
         c->chain_ok = !gate_off && !set_nonzero("BOSS_NO_CHAIN") && !set_nonzero("HIP_LAUNCH_BLOCKING");
@@ -201,9 +231,14 @@ static int ctx_init(Ctx* c) {
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 0;
-        static const int spare = getenv("BOSS_BULK_SPARE_CUS") ? atoi(getenv("BOSS_BULK_SPARE_CUS")) : 6;
-        c->bulk_wgs = std::max(0, cus - 2 - 8 - spare);      // every one of them must be resident at the same time: never more than the CUs that can be free
-        if (c->bulk_wgs < 32) c->bulk_wgs = 0;
+        // Every one of them must be resident at the same time, beside the chain's two and the strips' eight workgroups (whole CUs each).
+        // Workgroups are dealt to the XCDs by index and, inside an XCD, to its shader engines (8 CUs each) — and a workgroup whose
+        // engine is full WAITS there even when another engine has a free CU (measured: with 240 of them 8 residents never started, with
+        // 232 two, with 224 none).  Six per engine = 3/4 of the CUs leaves every engine two CUs for a strips and a chain workgroup
+        // whatever the deal (and for the panel solves and column updates, which then run unshared).  BOSS_BULK_WGS overrides.
+        if (cus > 0) c->n_cus = cus;
+        c->bulk_wgs = getenv("BOSS_BULK_WGS") ? atoi(getenv("BOSS_BULK_WGS")) : (cus / 8) * 6;
+        if (c->bulk_wgs < 32 || c->bulk_wgs > cus - 16) c->bulk_wgs = 0;
     }
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_llgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LLG_LDS_BYTES));
@@ -533,6 +568,23 @@ extern "C" int boss_debug_colupd_decode(int G, int k, int m, int ncols, int jfir
     }
     return BOSS_OK;
 }
+
+// Host-side walk of the resident trailing update's tile map (the same bulk_item / bulk_tiles the kernel calls): R0/C0/near of every
+// tile index of odd step o, and which of W workgroups owns it.  No device work (tests/test_abi_and_host.py).
+extern "C" int boss_debug_bulk_items(int nblk, int small_m, int o, int W, int cap, int* R0, int* C0, int* near, int* owner) {
+    const int T = bulk_tiles(nblk, o);
+    if (!R0 || !C0 || !near || !owner || W < 1) return -1;
+    for (int idx = 0; idx < T && idx < cap; ++idx) {
+        const BulkItem it = bulk_item(nblk, small_m, o, idx);
+        R0[idx] = it.R0;
+        C0[idx] = it.C0;
+        near[idx] = it.near;
+        owner[idx] = idx % W;
+    }
+    return T;
+}
+extern "C" int boss_debug_bulk_near_count(int nblk, int small_m, int o) { return bulk_near_count(nblk, small_m, o); }
+extern "C" int boss_debug_small_m(void) { return sched_small_m(); }
 
 #ifdef BOSS_CHAIN_TRACE
 // (tools/chain_trace3.py) read and reset the resident chain's device timeline

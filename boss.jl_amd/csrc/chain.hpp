@@ -123,7 +123,7 @@ __device__ __forceinline__ void chain_follow_phase(double* __restrict__ A, int l
     while (jb < 8) {
         if (!dead && seen <= jb) {
             bool got = false;
-            for (int it = 0; it < POLL_CAP; ++it) {               // (an LDS word of this workgroup: the polling wave posts 99 when it gives up)
+            for (int it = 0; it < POLL_CAP_LDS; ++it) {           // (an LDS word of this workgroup: the polling wave posts 99 when it gives up)
                 const int v = *seenw;
                 if (v > jb) {
                     seen = v;
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __res
     // The workgroup keeps its CU to itself: 16 waves × 128 registers fill every SIMD's register file, so no follower or bulk wave
     // can settle beside the pivot-chain wave (a co-resident wave on that SIMD stretches the chain 3980 -> 5450 cycles per panel).
     asm volatile("" ::: "v127");
+    if (tid == 0) __hip_atomic_fetch_add(as_global(sig + SIGW_UP), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (chain_ready_kernel)
     for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
         double* Ab = A + (size_t)b * BLK * ((size_t)ld + 1);
         // ---- block b with every panel < b-1 applied: the Gram matrix itself (b = 0, 1: the first follow kernel has started) or
@@ -314,6 +315,9 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
             note_giveup(8, k);
         }
         dead = true;
+        // (wave 1 waits on `avail` in LDS for the panels this wave sees: without the release it sat out its whole spin count in every
+        // step of a factorisation that had already been given up — the fallback of an N = 8192 update took most of a minute)
+        if (wave == 0 && lane == 0) *(volatile lds_int_t*)&avail = 99;
     };
     auto store_tile = [&](int jb, const v4d& t) {
 #pragma unroll
@@ -345,7 +349,7 @@ __device__ __forceinline__ void follow_strip(double* __restrict__ A, int ld, int
                 *(volatile lds_int_t*)&avail = 99;               // (releases wave 1)
             }
         } else {
-            for (int i = 0; i < POLL_CAP; ++i) {                  // (an LDS word of this workgroup: wave 0 posts 99 when it gives up)
+            for (int i = 0; i < POLL_CAP_LDS; ++i) {              // (an LDS word of this workgroup: wave 0 posts 99 when it gives up)
                 seen = *(volatile lds_int_t*)&avail;
                 if (seen > jb) {
                     asm volatile("" ::: "memory");
@@ -600,6 +604,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __re
     __shared__ v4d xs[TRSM_NA][64];
     __shared__ int ready, drained, avail;
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(sig + SIGW_UP), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (chain_ready_kernel)
     for (int k = 0; k + 1 < nblk; ++k) {
         // tile (k+1, k) carries every panel < k
         bool ok;
@@ -613,6 +618,18 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __re
         if (blockIdx.x == 0 && threadIdx.x == 64) g_ctrace[(k & 63) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
+}
+
+// Every workgroup of the resident kernels (chain 2, strips 8, trailing update W) counts itself into sig[SIGW_UP] when it starts.
+// This one-lane kernel sits on the main stream between the Gram kernel and the first panel solve and ends when all of them have:
+// the kernels behind it — hundreds of panel-solve workgroups per step that WAIT for the chain, two and more per CU from 64 block
+// columns on — would otherwise settle on every CU before a chain workgroup (a whole CU) had been placed, and wait for it for ever
+// (measured: most first updates at N = 8192 ended in the waits' time-out).  While the Gram kernel runs the resident workgroups
+// normally get placed anyway: the wait then costs one short launch.
+__global__ __launch_bounds__(64) void chain_ready_kernel(unsigned long long* __restrict__ sig, unsigned long long want,
+                                                         int* __restrict__ info, unsigned budget) {
+    if (threadIdx.x >= 64) return;
+    (void)poll_ge(sig + SIGW_UP, want, info, budget);
 }
 
 // Start-up probe (ctx_init): the chain schedule needs kernels of its four streams to run at the same time.  HIP maps streams to

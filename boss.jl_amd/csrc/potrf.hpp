@@ -140,6 +140,18 @@ __device__ __forceinline__ int ld_info(const int* p) {
 __device__ __forceinline__ void st_info(int* p, int v) {
     __hip_atomic_store((gmem_i32*)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The flag as memory holds it NOW, whatever this XCD's L2 has cached: an agent-scope read-modify-write executes at the memory side.
+// An sc1 LOAD is served by the XCD's L2, and the flag's line is not a hand-off line — the update's first kernel clears it with a
+// plain store, the log-det kernel writes its neighbours — so an L2 may keep a copy from before another XCD stored INT_MIN there.
+// A resident workgroup that polled the flag with loads then never saw the mark and sat out the full budget of EVERY later wait
+// (63 steps × 8 panels × the budget: the fallback of an N = 8192 update took minutes).  Used every 64th poll only.
+// (inline asm: LLVM folds an idempotent `atomicrmw or p, 0` back into the very load this replaces)
+__device__ __forceinline__ int ld_info_fresh(const int* p) {
+    int r;
+    const int zero = 0;
+    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"((gmem_i32*)(unsigned long long)p), "v"(zero) : "memory");
+    return r;
+}
 // 16 bytes per lane, write-through (there is no 16-byte atomic builtin).  The s_nop covers the wait state a VALU write to the
 // data registers needs behind a wide store: the compiler's hazard recogniser does not look inside inline asm.
 __device__ __forceinline__ void st_sc1_x4(double* p, v2d v) {
@@ -153,10 +165,21 @@ __device__ __forceinline__ void raise_word(unsigned long long* w, unsigned long 
 constexpr int SIGW_GATE = 0, SIGW_BULK = 3, SIGW_PANEL = 16, SIGW_WDONE = 32, SIGW_CRIT = 48, SIGW_NEAR = 8, SIGW_PROG = 64, SIGW_PROG_STRIDE = 16,
               SIGW_FDONE = SIGW_PROG + 8 * SIGW_PROG_STRIDE,   // (the eight strips' progress words: a line each — eight CUs store them, one wave polls all)
               SIGW_NEARCNT = SIGW_FDONE + 16,                  // resident trailing update (potrf_bulk_kernel): panels solved / near tiles delivered
-              SIG_WORDS = SIGW_NEARCNT + 16;
+              SIGW_UP = SIGW_NEARCNT + 16,                     // workgroups of the resident kernels that have started (chain_ready_kernel)
+              SIGW_DBG = SIGW_UP + 16,                    // BOSS_DEBUG_WATCH: [0] first give-up code, [1] give-ups, [2] last code, [4] waits ended by the mark, [5] by the clock
+              SIG_WORDS = SIGW_DBG + 16;
 // who gave up first (diagnostics: BOSS_CHAIN_VERBOSE prints it when an update falls back): code * 1000 + detail
 __device__ int g_giveup = 0;
-__device__ __forceinline__ void note_giveup(int code, int detail) { atomicCAS(&g_giveup, 0, code * 1000 + (detail & 511)); }
+__device__ unsigned long long* g_dbg = nullptr;             // BOSS_DEBUG_WATCH: the (host-mapped) signal block, for the watcher thread
+__device__ __forceinline__ void note_giveup(int code, int detail) {
+    atomicCAS(&g_giveup, 0, code * 1000 + (detail & 511));
+    unsigned long long* d = g_dbg;
+    if (d) {
+        atomicCAS(d + SIGW_DBG, 0ull, (unsigned long long)(code * 1000 + (detail & 511)));
+        atomicAdd(d + SIGW_DBG + 1, 1ull);
+        d[SIGW_DBG + 2] = (unsigned long long)(code * 1000 + (detail & 511));
+    }
+}
 // Bounded waits.  Every wait of the cross-kernel protocols gives up when `budget` ticks of the constant 100 MHz clock (s_memrealtime)
 // have passed since the wait began: the host derives the budget from the size of the system (≈ 20× the expected update time, at
 // least 20 ms: poll_budget_ticks, host_factor.inc), so that a caller whose device cannot run the kernels side by side (another
@@ -164,6 +187,7 @@ __device__ __forceinline__ void note_giveup(int code, int detail) { atomicCAS(&g
 // read every 64th poll; POLL_CAP bounds the loop count whatever the clock does.  A wait that gives up marks the factorisation
 // (info = INT_MIN: gp_finish repeats it on the next simpler schedule) and every other waiter notices the mark within 64 polls.
 constexpr int POLL_CAP = 1 << 26;
+constexpr int POLL_CAP_LDS = 1 << 22;                      // spins on an LDS word a sibling wave of the same workgroup posts (that wave's own waits are clocked)
 struct PollTimer {
     unsigned long long t0;
     unsigned budget;
@@ -172,8 +196,14 @@ struct PollTimer {
     // every 64th poll: 1 = out of time, 2 = somebody else gave up already, 0 = keep polling
     __device__ __forceinline__ int check(int i, const int* info) const {
         if ((i & 63) != 63) return 0;
-        if (ld_info(info) == INT_MIN) return 2;
-        return expired() ? 1 : 0;
+        unsigned long long* d = g_dbg;
+        if (ld_info_fresh(info) == INT_MIN) {
+            if (d && (threadIdx.x & 63) == 0) atomicAdd(d + SIGW_DBG + 4, 1ull);
+            return 2;
+        }
+        const bool out = expired();
+        if (out && d && (threadIdx.x & 63) == 0) atomicAdd(d + SIGW_DBG + 5, 1ull);
+        return out ? 1 : 0;
     }
 };
 // One wave waits until *w >= v (wave-uniform).  false: gave up (timeout, or another waiter already marked the factorisation).
@@ -1480,13 +1510,30 @@ __global__ __launch_bounds__(256) void potrf_bulk_kernel(double* __restrict__ A,
                                                          int* __restrict__ info, unsigned budget) {
     const int W = (int)gridDim.x, w = (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(sig + SIGW_UP), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (chain_ready_kernel)
     for (int e = 0; e + 1 < nblk; e += 2) {
         if (nblk - 1 - e <= small_m + 1) break;             // the single-stream tail takes over at this even step
         const int o = e + 1;
         const int T = bulk_tiles(nblk, o);
         if (T <= 0) break;
         if (wave == 0) {
-            (void)poll_ge(sig + SIGW_FDONE, fbase + o + 1, info, budget);   // (gave up: info is marked, carry on — every loop stays bounded)
+            // One SLOW poller per workgroup (≈ 3.4 µs between polls): these workgroups idle for half of every step, and a couple of hundred
+            // waves polling one line at the pace of the chain's own waits (s_sleep 1) congest the write-through / sc1 path every hand-off
+            // of the chain travels on — measured: the whole update 13× slower, the chain's 20 µs blocks 60-250 µs.
+            const PollTimer tm(budget);
+            bool ok = false;
+            for (int i = 0; i < POLL_CAP; ++i) {
+                if (ld_word(sig + SIGW_FDONE) >= fbase + o + 1) {
+                    ok = true;
+                    break;
+                }
+                if (tm.check(i, info)) break;
+                __builtin_amdgcn_s_sleep(127);
+            }
+            if (!ok && (threadIdx.x & 63) == 0) {             // (gave up: info is marked, carry on — every loop stays bounded)
+                st_info(info, INT_MIN);
+                note_giveup(9, o);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // the panels were written by kernels that ran while this one was resident
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
