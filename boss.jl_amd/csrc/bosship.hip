@@ -91,9 +91,8 @@ struct Ctx {
     // the resident panel chain (chain.hpp): its own stream, the base of its sequence numbers, and whether it may be used at all
     // (it needs kernels of different streams to run at the same time: off wherever launches are known to be serialised)
     hipStream_t chain_stream = nullptr, strip_stream = nullptr;
-    unsigned long long chain_seq = 0, crit_seq = 0, near_seq = 0, up_seq = 0;
+    unsigned long long chain_seq = 0, crit_seq = 0, up_seq = 0;
     int n_cus = 256;
-    int bulk_wgs = 0;                           // workgroups of the resident trailing update: one per CU, the chain's and the strips' CUs (and a few more) left free
     bool chain_ok = false;
     bool test_drop_chain = false;              // BOSS_TEST_DROP_CHAIN=1: the chain kernel is never launched (exercises the fallback)
     unsigned long long acq_seq = 0;            // sequence number of the arg-max result block (boss_acq_ei polls it)
@@ -178,7 +177,9 @@ static int ctx_init(Ctx* c) {
                 HIPCHK(hipHostMalloc((void**)&hp, SIG_WORDS * sizeof(unsigned long long), hipHostMallocMapped));
                 std::memset(hp, 0, SIG_WORDS * sizeof(unsigned long long));
                 HIPCHK(hipHostGetDevicePointer((void**)&c->sig_panel, hp, 0));
+#ifdef BOSS_DEBUG_WATCH_BUILD
                 HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(boss::g_dbg), &c->sig_panel, sizeof(void*)));
+#endif
                 std::thread([hp]() {
                     unsigned long long last[SIG_WORDS] = {0};
                     for (;;) {
@@ -187,9 +188,8 @@ static int ctx_init(Ctx* c) {
                         for (int i = 0; i < SIG_WORDS; ++i) now[i] = ((volatile unsigned long long*)hp)[i];
                         if (std::memcmp(now, last, sizeof now) == 0) continue;
                         std::memcpy(last, now, sizeof now);
-                        std::fprintf(stderr, "[bosship watch] up %llu wdone %llu panel %llu crit %llu | gate %llu near %llu bulk %llu | fdone %llu nearcnt %llu | strips",
-                                     now[SIGW_UP], now[SIGW_WDONE], now[SIGW_PANEL], now[SIGW_CRIT], now[SIGW_GATE], now[SIGW_NEAR], now[SIGW_BULK], now[SIGW_FDONE],
-                                     now[SIGW_NEARCNT]);
+                        std::fprintf(stderr, "[bosship watch] up %llu wdone %llu panel %llu crit %llu | gate %llu near %llu bulk %llu | strips",
+                                     now[SIGW_UP], now[SIGW_WDONE], now[SIGW_PANEL], now[SIGW_CRIT], now[SIGW_GATE], now[SIGW_NEAR], now[SIGW_BULK]);
                         for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %llu", now[SIGW_PROG + SIGW_PROG_STRIDE * q]);
                         std::fprintf(stderr, " | give-ups: first %llu n %llu last %llu; waits ended by mark %llu, by clock %llu", now[SIGW_DBG], now[SIGW_DBG + 1],
                                      now[SIGW_DBG + 2], now[SIGW_DBG + 4], now[SIGW_DBG + 5]);
@@ -227,18 +227,10 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_strips_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STRIPS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_bulk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BULK_LDS_BYTES));
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 0;
-        // Every one of them must be resident at the same time, beside the chain's two and the strips' eight workgroups (whole CUs each).
-        // Workgroups are dealt to the XCDs by index and, inside an XCD, to its shader engines (8 CUs each) — and a workgroup whose
-        // engine is full WAITS there even when another engine has a free CU (measured: with 240 of them 8 residents never started, with
-        // 232 two, with 224 none).  Six per engine = 3/4 of the CUs leaves every engine two CUs for a strips and a chain workgroup
-        // whatever the deal (and for the panel solves and column updates, which then run unshared).  BOSS_BULK_WGS overrides.
         if (cus > 0) c->n_cus = cus;
-        c->bulk_wgs = getenv("BOSS_BULK_WGS") ? atoi(getenv("BOSS_BULK_WGS")) : (cus / 8) * 6;
-        if (c->bulk_wgs < 32 || c->bulk_wgs > cus - 16) c->bulk_wgs = 0;
     }
     HIPCHK(hipFuncSetAttribute((const void*)small_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_llgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LLG_LDS_BYTES));
@@ -568,23 +560,6 @@ extern "C" int boss_debug_colupd_decode(int G, int k, int m, int ncols, int jfir
     }
     return BOSS_OK;
 }
-
-// Host-side walk of the resident trailing update's tile map (the same bulk_item / bulk_tiles the kernel calls): R0/C0/near of every
-// tile index of odd step o, and which of W workgroups owns it.  No device work (tests/test_abi_and_host.py).
-extern "C" int boss_debug_bulk_items(int nblk, int small_m, int o, int W, int cap, int* R0, int* C0, int* near, int* owner) {
-    const int T = bulk_tiles(nblk, o);
-    if (!R0 || !C0 || !near || !owner || W < 1) return -1;
-    for (int idx = 0; idx < T && idx < cap; ++idx) {
-        const BulkItem it = bulk_item(nblk, small_m, o, idx);
-        R0[idx] = it.R0;
-        C0[idx] = it.C0;
-        near[idx] = it.near;
-        owner[idx] = idx % W;
-    }
-    return T;
-}
-extern "C" int boss_debug_bulk_near_count(int nblk, int small_m, int o) { return bulk_near_count(nblk, small_m, o); }
-extern "C" int boss_debug_small_m(void) { return sched_small_m(); }
 
 #ifdef BOSS_CHAIN_TRACE
 // (tools/chain_trace3.py) read and reset the resident chain's device timeline

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void potrf_strips_kernel(double* __re
     }
 }
 
-// Every workgroup of the resident kernels (chain 2, strips 8, trailing update W) counts itself into sig[SIGW_UP] when it starts.
+// Every workgroup of the resident kernels (chain 2, strips 8) counts itself into sig[SIGW_UP] when it starts.
 // This one-lane kernel sits on the main stream between the Gram kernel and the first panel solve and ends when all of them have:
 // the kernels behind it — hundreds of panel-solve workgroups per step that WAIT for the chain, two and more per CU from 64 block
 // columns on — would otherwise settle on every CU before a chain workgroup (a whole CU) had been placed, and wait for it for ever

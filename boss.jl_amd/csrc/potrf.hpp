@@ -163,22 +163,25 @@ __device__ __forceinline__ void raise_word(unsigned long long* w, unsigned long 
 }
 // word indices inside the context's signal block (each group on a 128-byte line of its own)
 constexpr int SIGW_GATE = 0, SIGW_BULK = 3, SIGW_PANEL = 16, SIGW_WDONE = 32, SIGW_CRIT = 48, SIGW_NEAR = 8, SIGW_PROG = 64, SIGW_PROG_STRIDE = 16,
-              SIGW_FDONE = SIGW_PROG + 8 * SIGW_PROG_STRIDE,   // (the eight strips' progress words: a line each — eight CUs store them, one wave polls all)
-              SIGW_NEARCNT = SIGW_FDONE + 16,                  // resident trailing update (potrf_bulk_kernel): panels solved / near tiles delivered
-              SIGW_UP = SIGW_NEARCNT + 16,                     // workgroups of the resident kernels that have started (chain_ready_kernel)
+              SIGW_UP = SIGW_PROG + 8 * SIGW_PROG_STRIDE,      // (the eight strips' progress words: a line each — eight CUs store them, one wave polls all)
+                                                               // SIGW_UP: workgroups of the resident kernels that have started (chain_ready_kernel)
               SIGW_DBG = SIGW_UP + 16,                    // BOSS_DEBUG_WATCH: [0] first give-up code, [1] give-ups, [2] last code, [4] waits ended by the mark, [5] by the clock
               SIG_WORDS = SIGW_DBG + 16;
 // who gave up first (diagnostics: BOSS_CHAIN_VERBOSE prints it when an update falls back): code * 1000 + detail
 __device__ int g_giveup = 0;
-__device__ unsigned long long* g_dbg = nullptr;             // BOSS_DEBUG_WATCH: the (host-mapped) signal block, for the watcher thread
+#ifdef BOSS_DEBUG_WATCH_BUILD
+__device__ unsigned long long* g_dbg = nullptr;             // diagnostics build (tools/): the host-mapped signal block, for the watcher thread
+#endif
 __device__ __forceinline__ void note_giveup(int code, int detail) {
     atomicCAS(&g_giveup, 0, code * 1000 + (detail & 511));
+#ifdef BOSS_DEBUG_WATCH_BUILD
     unsigned long long* d = g_dbg;
     if (d) {
         atomicCAS(d + SIGW_DBG, 0ull, (unsigned long long)(code * 1000 + (detail & 511)));
         atomicAdd(d + SIGW_DBG + 1, 1ull);
         d[SIGW_DBG + 2] = (unsigned long long)(code * 1000 + (detail & 511));
     }
+#endif
 }
 // Bounded waits.  Every wait of the cross-kernel protocols gives up when `budget` ticks of the constant 100 MHz clock (s_memrealtime)
 // have passed since the wait began: the host derives the budget from the size of the system (≈ 20× the expected update time, at
@@ -196,13 +199,20 @@ struct PollTimer {
     // every 64th poll: 1 = out of time, 2 = somebody else gave up already, 0 = keep polling
     __device__ __forceinline__ int check(int i, const int* info) const {
         if ((i & 63) != 63) return 0;
-        unsigned long long* d = g_dbg;
-        if (ld_info_fresh(info) == INT_MIN) {
-            if (d && (threadIdx.x & 63) == 0) atomicAdd(d + SIGW_DBG + 4, 1ull);
-            return 2;
+        if (ld_info(info) == INT_MIN) return 2;
+        // (the memory-side read is an atomic on ONE word: every 64th poll from the hundreds of panel-solve workgroups of a step it
+        // serialised behind itself and cost the N = 4096 update 0.1 ms — every 1024th poll only, i.e. in waits of a millisecond and more)
+        if ((i & 1023) == 1023) {
+            const int v = ld_info_fresh(info);
+#ifdef BOSS_DEBUG_WATCH_BUILD
+            if (v == INT_MIN && g_dbg && (threadIdx.x & 63) == 0) atomicAdd(g_dbg + SIGW_DBG + 4, 1ull);
+#endif
+            if (v == INT_MIN) return 2;
         }
         const bool out = expired();
-        if (out && d && (threadIdx.x & 63) == 0) atomicAdd(d + SIGW_DBG + 5, 1ull);
+#ifdef BOSS_DEBUG_WATCH_BUILD
+        if (out && g_dbg && (threadIdx.x & 63) == 0) atomicAdd(g_dbg + SIGW_DBG + 5, 1ull);
+#endif
         return out ? 1 : 0;
     }
 };
@@ -1295,39 +1305,6 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k,
             }
 }
 
-// The same with the store flavour chosen at run time (the resident trailing update: one code path for its near and far tiles).
-template <class G>
-__device__ __forceinline__ void syrk_tile_dyn(double* __restrict__ A, int ld, int k, int R0, int C0, int K, bool sc1) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / G::WC, wc = wave % G::WC;
-    const double* Pi = A + R0 + (size_t)k * BLK * ld;
-    const double* Pj = A + C0 + (size_t)k * BLK * ld;
-    double* C = A + R0 + (size_t)C0 * ld;
-    v4d acc[G::TM][G::TN];
-#pragma unroll
-    for (int m = 0; m < G::TM; m += 2)
-#pragma unroll
-        for (int n = 0; n < G::TN; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v2d c2 = *reinterpret_cast<const v2d*>(C + G::row_of(wr, m, lane) + (size_t)G::col_of(wc, n, i, lane) * ld);
-                acc[m][n][i] = c2[0];
-                acc[m + 1][n][i] = c2[1];
-            }
-    G::template run<-1>(Pi, ld, Pj, ld, K, acc);
-#pragma unroll
-    for (int m = 0; m < G::TM; m += 2)
-#pragma unroll
-        for (int n = 0; n < G::TN; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v2d c2 = {acc[m][n][i], acc[m + 1][n][i]};
-                double* dst = C + G::row_of(wr, m, lane) + (size_t)G::col_of(wc, n, i, lane) * ld;
-                if (sc1) st_sc1_x4(dst, c2);
-                else *reinterpret_cast<v2d*>(dst) = c2;
-            }
-}
-
 // Trailing update behind panel k over the block triangle that starts at block `first` and has m
 // square block rows (+ the δ^T row block at first+m == Np/128):  C_ij -= P_i P_j^T.
 //   potrf_syrk_kernel   all of it (first = k+1) or, with look-ahead, everything beyond the next
@@ -1419,11 +1396,7 @@ __host__ __device__ inline ColupdWork colupd_decode(int t, int G, int k, int m, 
 __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict__ Abase, int ld, size_t bstride, int k,
                                                               int m, int ncols, int jfirst, int npan,
                                                               unsigned long long* wword, unsigned long long wval, int* info,
-                                                              int skipdiag, int xblk, unsigned long long* critw, unsigned budget,
-                                                              unsigned long long* fword = nullptr, unsigned long long fval = 0) {
-    // fword: this kernel's start says "every panel solve enqueued before it has completed" to the resident trailing update
-    // (potrf_bulk_kernel, released by this word instead of a gate kernel on its stream) — raised BEFORE the wait below
-    if (fword && blockIdx.x == 0 && threadIdx.x == 0) raise_word(fword, fval);
+                                                              int skipdiag, int xblk, unsigned long long* critw, unsigned budget) {
 #ifdef BOSS_CHAIN_TRACE
     if (threadIdx.x == 0) atomicMin(&g_cutrace[(k & 63) * 4 + 0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     struct TraceEnd { int k; __device__ ~TraceEnd() { if (threadIdx.x == 0) atomicMax(&g_cutrace[(k & 63) * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } trace_end_{k};
@@ -1450,120 +1423,6 @@ __global__ __launch_bounds__(256, 2) void potrf_colupd_kernel(double* __restrict
     }
     if (npan == 2) syrk_tile<RhsG>(A, ld, k - 1, w.R0, w.C0, 2 * BLK);
     else syrk_tile<RhsG>(A, ld, k, w.R0, w.C0);
-}
-
-// ------------------------------------------------------------------------------------------
-// The trailing update of the paired look-ahead schedule as ONE resident kernel (chain schedule, single matrices).
-// Replaces, per odd step o, the launches  gate -> near(o) -> publish -> far(o) -> publish  on the side stream: each ramped 256
-// one-workgroup CUs up and down, started only when the column update of step o had ended and a gate kernel had seen it, and
-// its 64×128 tiles arrived as one burst that held every CU's slots.  Here W workgroups (one per CU, the chain's and the strips'
-// CUs left free) stay resident for the whole paired phase and walk the steps themselves:
-//   * the work of step o (panels o-1, o applied to every column >= o+3, K = 256) is cut into half tiles (64 rows × 128 columns;
-//     the δ^T rows of a column count as one more half tile); half tile (h, j) — rows 64h.., block column j — has the index
-//     idx = n(n+2) + h - 2j, n = nblk-1-j, in the enumeration "last column first", so the tiles alive at step o are exactly
-//     idx < T(o) = n(n+2) with n = nblk-3-o, and workgroup w OWNS the tiles idx ≡ w (mod W): balanced to within one tile at every
-//     step, and a tile is read and written by the same workgroup at every step — plain loads and stores, no hand-off;
-//   * a workgroup starts step o when sig[SIGW_FDONE] says the panel solve of step o has completed (raised by the entry of the
-//     column-update kernel behind it: no gate kernel, and the update runs BESIDE that column update instead of behind it), and
-//     takes its tiles nearest to the chain first (descending idx): columns o+3, o+4 and tile (o+5, o+5) are what the column
-//     update of step o+2 reads next — those go out write-through (sc1) and are counted into sig[SIGW_NEARCNT], which that
-//     column update waits for (wait_word: poll, acquire).  In the last pair before the single-stream tail every tile is "near".
-// Same arithmetic as the launches it replaces: every element receives its panels in ascending k — bit-identical results.
-// All waits are bounded (PollTimer); a workgroup that gives up marks the factorisation and carries on without waiting.
-// ------------------------------------------------------------------------------------------
-struct BulkItem {
-    int R0, C0;               // R0 < 0: nothing to do (tile (o+3, o+3): the column update of step o took it)
-    int near;                 // stored write-through and counted
-};
-// step o (odd), tile index idx < bulk_tiles(nblk, o)
-__host__ __device__ inline int bulk_tiles(int nblk, int o) {
-    const int n = nblk - 3 - o;
-    return n > 0 ? n * (n + 2) : 0;
-}
-__host__ __device__ inline BulkItem bulk_item(int nblk, int small_m, int o, int idx) {
-    int r = (int)sqrt((double)(idx + 1));                    // r = n_j + 1, (r² - 1) <= idx < (r+1)² - 1
-    while ((r + 1) * (r + 1) <= idx + 1) ++r;
-    while (r * r > idx + 1) --r;
-    const int j = nblk - r, h = 2 * j + (idx - (r * r - 1));
-    const bool last_pair = nblk - 2 - o <= small_m + 1, split = !last_pair && nblk - 3 - o > 2;
-    const bool delta = h == 2 * nblk, diag = !delta && (h >> 1) == j;
-    BulkItem it;
-    it.R0 = delta ? nblk * BLK : h * 64;
-    it.C0 = j * BLK;
-    it.near = (!split || j < o + 5 || (diag && j == o + 5)) ? 1 : 0;
-    if (diag && j == o + 3) it.R0 = -1;
-    return it;
-}
-// near tiles of step o (what sig[SIGW_NEARCNT] advances by)
-__host__ __device__ inline int bulk_near_count(int nblk, int small_m, int o) {
-    int c = 0;
-    const int T = bulk_tiles(nblk, o);
-    for (int idx = 0; idx < T; ++idx) {
-        const BulkItem it = bulk_item(nblk, small_m, o, idx);
-        c += (it.R0 >= 0 && it.near) ? 1 : 0;
-    }
-    return c;
-}
-constexpr int BULK_LDS_BYTES = 81 * 1024;                   // occupancy limiter: one resident workgroup per CU, none beside the strips (90 KB)
-__global__ __launch_bounds__(256) void potrf_bulk_kernel(double* __restrict__ A, int ld, int nblk, int small_m,
-                                                         unsigned long long* __restrict__ sig, unsigned long long fbase,
-                                                         int* __restrict__ info, unsigned budget) {
-    const int W = (int)gridDim.x, w = (int)blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(sig + SIGW_UP), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (chain_ready_kernel)
-    for (int e = 0; e + 1 < nblk; e += 2) {
-        if (nblk - 1 - e <= small_m + 1) break;             // the single-stream tail takes over at this even step
-        const int o = e + 1;
-        const int T = bulk_tiles(nblk, o);
-        if (T <= 0) break;
-        if (wave == 0) {
-            // One SLOW poller per workgroup (≈ 3.4 µs between polls): these workgroups idle for half of every step, and a couple of hundred
-            // waves polling one line at the pace of the chain's own waits (s_sleep 1) congest the write-through / sc1 path every hand-off
-            // of the chain travels on — measured: the whole update 13× slower, the chain's 20 µs blocks 60-250 µs.
-            const PollTimer tm(budget);
-            bool ok = false;
-            for (int i = 0; i < POLL_CAP; ++i) {
-                if (ld_word(sig + SIGW_FDONE) >= fbase + o + 1) {
-                    ok = true;
-                    break;
-                }
-                if (tm.check(i, info)) break;
-                __builtin_amdgcn_s_sleep(127);
-            }
-            if (!ok && (threadIdx.x & 63) == 0) {             // (gave up: info is marked, carry on — every loop stays bounded)
-                st_info(info, INT_MIN);
-                note_giveup(9, o);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // the panels were written by kernels that ran while this one was resident
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        int cnt = 0;                                         // near tiles stored and not yet counted in
-        auto deliver = [&]() {
-            drain_stores();                                  // every storing wave, then one lane counts the workgroup's near tiles in
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(sig + SIGW_NEARCNT), (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cnt = 0;
-#ifdef BOSS_CHAIN_TRACE
-            if (threadIdx.x == 0) atomicMax(&g_cutrace[(o & 63) * 4 + 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // last near tile of step o out
-#endif
-        };
-        if (w < T) {
-            for (int idx = T - 1 - (T - 1 - w) % W; idx >= 0; idx -= W) {     // this workgroup's tiles, nearest to the chain first
-                const BulkItem it = bulk_item(nblk, small_m, o, idx);
-                const int R0 = __builtin_amdgcn_readfirstlane(it.R0), C0 = __builtin_amdgcn_readfirstlane(it.C0);
-                const bool nr = __builtin_amdgcn_readfirstlane(it.near) != 0;
-                if (R0 < 0) continue;
-                if (!nr && cnt) deliver();                   // (the near tiles come first: they are out before the first far tile starts)
-                syrk_tile_dyn<SyrkHalfG>(A, ld, o - 1, R0, C0, 2 * BLK, nr);
-                cnt += nr ? 1 : 0;
-            }
-        }
-        if (cnt) deliver();
-#ifdef BOSS_CHAIN_TRACE
-        if (threadIdx.x == 0) atomicMax(&g_cutrace[(o & 63) * 4 + 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());       // last tile of step o done
-#endif
-    }
 }
 
 // Block-row variant for boss_gp_append: behind panel k update ONLY block row kb (4 strips of

@@ -168,12 +168,12 @@ def test_asm_ring_kernels_do_not_spill(tmp_path):
     found = 0
     for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)", txt, re.S):
         agpr, name, scratch, vgpr = int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(4))
-        if any(k in name for k in ("predict_kernel", "backsolve_kernel", "potrf_syrk", "potrf_colupd", "potrf_rowupd", "potrf_bulk", "linv_level",
+        if any(k in name for k in ("predict_kernel", "backsolve_kernel", "potrf_syrk", "potrf_colupd", "potrf_rowupd", "linv_level",
                                    "kinv_syrk", "linvt_kernel", "few_update", "few_back_update", "few_finish", "few_back_finish", "inv_fwd_kernel",
                                    "inv_bwd_kernel")):
             found += 1
             assert agpr == 0 and scratch == 0 and vgpr <= 256, (name, agpr, scratch, vgpr)
-    assert found >= 20
+    assert found >= 19
 
 
 def test_integration_doc_shows_the_shipped_julia_glue():
@@ -300,85 +300,3 @@ def test_column_update_takes_every_strip_exactly_once():
                     G = (4 * (m - 2) + 1) + (4 * (m - 3) + 1) + 4
                     check(walk(G, k, m, 2, 2, 1, k + 5, 0), expect(k, m, [2, 3], 1, k + 5), 0, False)
 
-
-def test_resident_trailing_update_covers_every_tile_once():
-    """The chain schedule with the resident trailing update (potrf_bulk_kernel), replayed on the host through the maps the kernels
-    themselves use (colupd_decode, bulk_item): every 32-row strip of every block column — and its δ^T row — receives every earlier
-    panel exactly once and in ascending order (the diagonal tile's last panel comes from the chain kernel), the strips a column
-    update reads are complete when it runs, every tile is owned by one workgroup for the whole factorisation, and the near-tile
-    counts the column updates wait for are the counts the workgroups deliver."""
-    import ctypes as C
-    from boss_jl_amd import api
-    lib = api.load_library()
-    dec = lib.boss_debug_colupd_decode
-    dec.restype = C.c_int
-    dec.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_int)] * 3
-    items = lib.boss_debug_bulk_items
-    items.restype = C.c_int
-    items.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 4
-    lib.boss_debug_bulk_near_count.restype = C.c_int
-    lib.boss_debug_bulk_near_count.argtypes = [C.c_int] * 3
-    small_m = lib.boss_debug_small_m()
-    BLK = 128
-
-    def colupd(applied, nblk, G, k, m, ncols, jfirst, npan, skipdiag, xblk, crit):
-        R0, C0, cr = (C.c_int * G)(), (C.c_int * G)(), (C.c_int * G)()
-        assert dec(G, k, m, ncols, jfirst, skipdiag, xblk, crit, R0, C0, cr) == 0
-        for t in range(G):
-            if R0[t] < 0:
-                continue
-            key = (R0[t] // 32, C0[t] // BLK)
-            for p in range(k - npan + 1, k + 1):
-                applied.setdefault(key, []).append(p)
-
-    for nblk in list(range(12, 40)) + [48, 64]:
-        W = 192
-        applied, owner = {}, {}
-        near_total = 0
-        k = 0
-        while k + 1 < nblk and nblk - 1 - k > small_m + 1:                    # paired phase (potrf_enqueue, chain schedule)
-            for kk in (k, k + 1):
-                m = nblk - 1 - kk
-                if kk == k:
-                    xblk = kk + 2 if m >= 2 else -1
-                    colupd(applied, nblk, 4 * m + 1 + (4 if xblk >= 0 else 0), kk, m, 1, 0, 1, 1, xblk, 1)
-                else:
-                    nc = 2 if m >= 2 else 1
-                    xblk = kk + 3 if m - 2 > 0 else -1
-                    # what this column update reads must be complete: columns kk+1 (and kk+2) carry every panel < kk-1 (its own pair comes now)
-                    for (r, j), ps in applied.items():
-                        if j in (kk + 1, kk + 2) and r >= 4 * j:
-                            want = list(range(0, kk - 1))
-                            if j == kk + 1 and r < 4 * j + 4:
-                                want = list(range(0, kk))                      # tile (kk+1, kk+1): panel kk-1 came with the even step's extra strips
-                            assert ps == want, (nblk, kk, r, j, ps)
-                    colupd(applied, nblk, (4 * m + 1) + (4 * (m - 1) + 1 if nc == 2 else 0) + (4 if xblk >= 0 else 0), kk, m, nc, 0, 2, 1, xblk, 1)
-                    if m - 2 > 0:                                              # the resident workgroups take step kk
-                        T = 4 * nblk * nblk
-                        R0, C0, nr, ow = (C.c_int * T)(), (C.c_int * T)(), (C.c_int * T)(), (C.c_int * T)()
-                        n = items(nblk, small_m, kk, W, T, R0, C0, nr, ow)
-                        assert 0 < n <= T
-                        cnt = 0
-                        for idx in range(n):
-                            key = (R0[idx] // 64 if R0[idx] >= 0 else None, C0[idx] // BLK)
-                            if R0[idx] < 0:
-                                continue
-                            assert owner.setdefault(key, ow[idx]) == ow[idx], "a tile changes its owner between steps"
-                            cnt += nr[idx]
-                            rows = [R0[idx] // 32] if R0[idx] == nblk * BLK else [R0[idx] // 32, R0[idx] // 32 + 1]
-                            for r in rows:
-                                for p in (kk - 1, kk):
-                                    applied.setdefault((r, C0[idx] // BLK), []).append(p)
-                        assert cnt == lib.boss_debug_bulk_near_count(nblk, small_m, kk)
-                        near_total += cnt
-            k += 2
-        for kt in range(k, nblk - 1):                                          # single-stream tail
-            m = nblk - 1 - kt
-            colupd(applied, nblk, 2 * m * (m + 1) + m, kt, m, m, 0, 1, 1, -1, 1)
-        for j in range(1, nblk):                                               # the chain kernel applies panel j-1 to tile (j, j)
-            for r in range(4 * j, 4 * j + 4):
-                applied.setdefault((r, j), []).append(j - 1)
-        for j in range(1, nblk):
-            for r in list(range(4 * j, 4 * nblk)) + [4 * nblk]:
-                assert applied.get((r, j)) == list(range(j)), (nblk, r, j, applied.get((r, j)))
-        assert all(j >= 1 and (r >= 4 * j) for (r, j) in applied), "an update outside the trailing matrix"

@@ -50,13 +50,13 @@ def main():
     t0 = min(vals)
     us = lambda v: "       " if not (0 < int(v) < 2**63) else f"{(int(v) - t0) / 100.0:7.1f}"
     print(f"N={N}: update {dt * 1e3:.3f} ms (host); µs from the first stamp")
-    print(" k | blk ready  F first  F last   C start  C end  | strip0: start late end | S entry  S exit | U entry  U exit | bulk: near out, done | period")
+    print(" k | blk ready  F first  F last   C start  C end  | strip0: start late end | S entry  S exit | U entry  U exit | period")
     prev = None
     for k in range(nblk):
         r = ch[k]
         per = "" if prev is None or not r[4] else f"{(int(r[4]) - prev) / 100.0:6.1f}"
         prev = int(r[4]) if r[4] else prev
-        print(f"{k:2d} | {us(r[0])} {us(r[1])} {us(r[2])} {us(r[3])} {us(r[4])} |  {us(r[8])}  {int(r[7])}  {us(r[10])} | {us(r[5])} {us(r[9])} | {us(cu[k][0])} {us(cu[k][1])} | {us(cu[k][2])} {us(cu[k][3])} | {per}")
+        print(f"{k:2d} | {us(r[0])} {us(r[1])} {us(r[2])} {us(r[3])} {us(r[4])} |  {us(r[8])}  {int(r[7])}  {us(r[10])} | {us(r[5])} {us(r[9])} | {us(cu[k][0])} {us(cu[k][1])} | {per}")
     print("boundary detail (µs after the previous block's C end): strips end, F sees last panel, operands landed, tiles written, C start")
     for k in range(max(2, nblk - 6), nblk):
         e = int(ch[k - 1][4])
