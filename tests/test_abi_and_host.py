@@ -300,3 +300,63 @@ def test_column_update_takes_every_strip_exactly_once():
                     G = (4 * (m - 2) + 1) + (4 * (m - 3) + 1) + 4
                     check(walk(G, k, m, 2, 2, 1, k + 5, 0), expect(k, m, [2, 3], 1, k + 5), 0, False)
 
+
+def test_chain_schedules_apply_every_panel_once_in_order():
+    """The trailing-update schedules that run beside the resident chain (potrf_enqueue, BOSS_CHAIN_TRAIL = 0 and 1), replayed on the
+    host through the workgroup -> strip map the kernel itself uses: every 32-row strip of every block column, and its δ^T row,
+    receives every earlier panel exactly once and in ascending order (the last panel of a diagonal tile comes from the chain
+    kernel) — which is also why all schedules give bit-identical factors — and every diagonal tile has all panels but its last one
+    when the step before its own factorisation ends."""
+    import ctypes as C
+    from boss_jl_amd import api
+    lib = api.load_library()
+    dec = lib.boss_debug_colupd_decode
+    dec.restype = C.c_int
+    dec.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_int)] * 3
+    BLK = 128
+
+    def colupd(applied, G, k, m, ncols, jfirst, npan, skipdiag, xblk, crit):
+        R0, C0, cr = (C.c_int * G)(), (C.c_int * G)(), (C.c_int * G)()
+        assert dec(G, k, m, ncols, jfirst, skipdiag, xblk, crit, R0, C0, cr) == 0
+        seen = set()
+        for t in range(G):
+            if R0[t] < 0:
+                continue
+            key = (R0[t] // 32, C0[t] // BLK)
+            assert key not in seen, "a strip is taken by two workgroups of one launch"
+            seen.add(key)
+            for p in range(k - npan + 1, k + 1):
+                applied.setdefault(key, []).append(p)
+        if m >= 2:
+            assert sum(cr[t] for t in range(G) if R0[t] >= 0) == 8 and all(cr[t] for t in range(8))
+
+    for mode in (0, 1):
+        for nblk in range(3, 41):
+            applied = {}
+
+            def diag_ready(j, upto):                          # tile (j, j) carries the panels 0 .. upto-1
+                for r in range(4 * j, 4 * j + 4):
+                    assert applied.get((r, j), []) == list(range(upto)), (mode, nblk, j, applied.get((r, j)))
+
+            k = 0
+            if mode == 1:
+                while k + 3 < nblk:
+                    m = nblk - 1 - k
+                    colupd(applied, 4 * m + 1 + 4, k, m, 1, 0, 1, 1, k + 2, 1)
+                    diag_ready(k + 2, k + 1)                  # F(k+2) adds panel k+1 during step k+1
+                    m = nblk - 2 - k
+                    colupd(applied, 2 * m * (m + 1) + m, k + 1, m, m, 0, 2, 1, -1, 1)
+                    diag_ready(k + 3, k + 2)
+                    k += 2
+            for kt in range(k, nblk - 1):
+                m = nblk - 1 - kt
+                colupd(applied, 2 * m * (m + 1) + m, kt, m, m, 0, 1, 1, -1, 1)
+                if kt + 2 < nblk:
+                    diag_ready(kt + 2, kt + 1)
+            for j in range(1, nblk):                           # the chain kernel applies panel j-1 to tile (j, j)
+                for r in range(4 * j, 4 * j + 4):
+                    applied.setdefault((r, j), []).append(j - 1)
+            for j in range(1, nblk):
+                for r in list(range(4 * j, 4 * nblk)) + [4 * nblk]:
+                    assert applied.get((r, j)) == list(range(j)), (mode, nblk, r, j, applied.get((r, j)))
+            assert all(j >= 1 and r >= 4 * j for (r, j) in applied)
