@@ -68,6 +68,10 @@ static hipError_t dev_malloc(void** p, size_t bytes) {
     return e;
 }
 
+// doubles into the 4 KiB pinned result block (its head: {max, arg-max, sequence number} of boss_acq_ei)
+constexpr size_t MULTI_RES_OFF = 384;   // (max, arg-max) of a deferred multi-device shard
+constexpr size_t FEW_RES_OFF = 400;     // {μ[4], σ²[4], bad, seq} of a one-to-four-candidates prediction
+
 struct Workspace {
     void* p = nullptr;
     size_t bytes = 0;
@@ -96,6 +100,7 @@ struct Ctx {
     bool chain_ok = false;
     bool test_drop_chain = false;              // BOSS_TEST_DROP_CHAIN=1: the chain kernel is never launched (exercises the fallback)
     unsigned long long acq_seq = 0;            // sequence number of the arg-max result block (boss_acq_ei polls it)
+    unsigned long long few_seq = 0;            // ... of the few-candidates prediction's result block (boss_gp_predict)
     bool lookahead = true;
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;

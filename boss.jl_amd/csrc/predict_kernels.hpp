@@ -635,6 +635,7 @@ __global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* _
 // ------------------------------------------------------------------------------------------
 constexpr int WINV_ROWS = 8;                                  // rows k per workgroup (two per wave)
 constexpr int WINV_MAX_M = WINV_MAX_M_DECL;
+constexpr int FEW_ARGS_MAX_D = 16;                          // x_dim up to which few candidates / one appended point travel in kernel arguments
 template <int MC>                                            // candidates staged per call: 1, 2 or 4
 __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict__ U, int ldu, int Np,
                                                         const double* __restrict__ Afac, int ld,
@@ -862,7 +863,8 @@ __global__ __launch_bounds__(256) void linv_col_gemv_kernel(const double* __rest
 // a non-positive d² is reported like a failed pivot (info = N0 + 1).
 __global__ __launch_bounds__(256) void append_scalars_kernel(const double* __restrict__ part, int nwg, const double* __restrict__ hyp,
                                                              const double* __restrict__ y, const double* __restrict__ mean, int N0,
-                                                             double* __restrict__ scal, double* __restrict__ dz, int* __restrict__ info) {
+                                                             double* __restrict__ scal, double* __restrict__ dz, int* __restrict__ info,
+                                                             double* __restrict__ host_out = nullptr, unsigned long long res_seq = 0) {
     __shared__ double red[2][256];
     const int tid = threadIdx.x;
     double s = 0.0, z = 0.0;
@@ -888,6 +890,37 @@ __global__ __launch_bounds__(256) void append_scalars_kernel(const double* __res
         dz[1] = zn;
         scal[0] += 2.0 * log(dd);
         scal[1] = __builtin_fma(zn, zn, scal[1]);
+        if (host_out) {
+            // the caller's answer (log-likelihood, status) is known HERE: it goes to mapped host memory now, and the host returns while the
+            // second pass over the inverse factors and the patches are still running (everything that follows is ordered on the stream)
+            host_out[0] = scal[0];
+            host_out[1] = scal[1];
+            reinterpret_cast<int*>(host_out + 2)[0] = *info;
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + 3), res_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// One new observation whose coordinates (raw and scaled), value and prior mean travel in the kernel arguments (boss_gp_append with
+// n = 1 on resident inverse factors): written into the handle's point / observation arrays, failed-pivot flag cleared — instead
+// of three small uploads and a stream synchronisation in front of the append.
+struct AppendPoint {
+    int d, N0, Np;
+    double y, mean;
+    double raw[FEW_ARGS_MAX_D], sc[FEW_ARGS_MAX_D];
+};
+__global__ __launch_bounds__(64) void append_point_kernel(AppendPoint par, double* __restrict__ Xraw, double* __restrict__ Xsc,
+                                                          double* __restrict__ y, double* __restrict__ mean, int* __restrict__ info) {
+    const int k = threadIdx.x;
+    if (k < par.d) {
+        Xraw[(size_t)k * par.Np + par.N0] = par.raw[k];
+        Xsc[(size_t)k * par.Np + par.N0] = par.sc[k];
+    }
+    if (k == 0) {
+        y[par.N0] = par.y;
+        mean[par.N0] = par.mean;
+        *info = 0;
     }
 }
 
@@ -936,6 +969,76 @@ __global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restri
         const double s = red[2 * tid][0], z = red[2 * tid + 1][0];
         mu[tid] = (mean_s ? mean_s[tid] : 0.0) + z;
         var[tid] = mode == 2 ? -s : mode == 1 ? fmax(0.0, amp2 - s) : amp2 - s + PREDICT_JITTER;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One to four candidates per call on resident inverse factors, the reference's own call pattern (`acq.(eachcol(xs))` evaluates one
+// point at a time: expected_improvement.jl:75,79; every objective evaluation of an Optimization.jl maximiser is such a call).  The
+// call is latency, not work: 21 µs of it is the pass over L⁻ᵀ, the rest used to be two copies, five launches and a stream
+// synchronisation.  Here the (host-scaled) candidates and their prior means travel in the kernel ARGUMENTS, K* is evaluated by
+// kstar_args_kernel, and winv_finish_host_kernel clips the variances (_clip_var, gaussian_process.jl:186-194) and writes
+// {μ, σ², first bad index} and then a sequence number into mapped host memory, which the host polls: three launches, no copy.
+// ------------------------------------------------------------------------------------------
+struct FewCand {
+    int ncols;
+    double x[WINV_MAX_M][FEW_ARGS_MAX_D];                    // scaled (and, for DiscreteKernel dims, rounded) coordinates
+    double mean[WINV_MAX_M];                                 // prior mean at the candidates
+};
+__global__ __launch_bounds__(256) void kstar_args_kernel(FewCand par, const double* __restrict__ Xsc, int Np, int N, int d, int kern,
+                                                         double amp2, double* __restrict__ kst) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double r2[WINV_MAX_M];
+#pragma unroll
+    for (int c = 0; c < WINV_MAX_M; ++c) r2[c] = 0.0;
+    for (int kd = 0; kd < d; ++kd) {
+        const double xr = Xsc[(size_t)kd * Np + row];
+#pragma unroll
+        for (int c = 0; c < WINV_MAX_M; ++c) {
+            const double df = xr - par.x[c][kd];
+            r2[c] = __builtin_fma(df, df, r2[c]);
+        }
+    }
+    const bool live = row < N;
+#pragma unroll
+    for (int c = 0; c < WINV_MAX_M; ++c)
+        if (c < par.ncols) kst[(size_t)row * 32 + c] = live ? amp2 * kappa_r2(kern, r2[c]) : 0.0;
+}
+// host_out (mapped host memory): [0..4) μ, [4..8) σ² (clipped), [8] first index whose variance is below -1e-8 (or -1), [9] sequence number
+__global__ __launch_bounds__(256) void winv_finish_host_kernel(const double* __restrict__ part, int nwg, FewCand par, double amp2,
+                                                               double* __restrict__ host_out, unsigned long long seq) {
+    __shared__ double red[8][256];
+    const int tid = threadIdx.x, M = par.ncols;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (int w = tid; w < nwg; w += 256)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += part[(size_t)w * 8 + q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[q][tid] = acc[q];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {               // fixed-order tree: deterministic (same as winv_finish_kernel)
+        if (tid < off)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[q][tid] += red[q][tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        long long bad = -1;
+        for (int j = 0; j < M; ++j) {
+            const double s = red[2 * j][0], z = red[2 * j + 1][0];
+            double v = amp2 - s + PREDICT_JITTER;
+            if (!(v >= 0.0)) {                                // (NaN counts as offending, as in clip_var_kernel)
+                if (v >= -MAX_NEG_VAR) v = 0.0;
+                else if (bad < 0) bad = j;                    // DomainError: the value stays as it is (boss_gp_predict reports it)
+            }
+            host_out[j] = par.mean[j] + z;
+            host_out[4 + j] = v;
+        }
+        reinterpret_cast<long long*>(host_out)[8] = bad;
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out) + 9, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
