@@ -704,6 +704,20 @@ def main():
         note("CPU baseline (oracle on the host cores)")
         cpu = cpu_baseline(X, y, Xs, lam)
 
+    if rank == 0 and acq_by_m:
+        # configs[2] as written shards 8192 candidates over EIGHT GPUs: every rank repeats the update and takes M/8 = 1024 candidates on
+        # the fresh factorisation.  What one step then costs per rank, from this run's own single-GPU measurements (the exchange is a
+        # 16-byte all-gather, priced at 0.03 ms: an assumption, no multi-GPU box has been available) — the design ceiling of the strong record.
+        ms_u = s_upd / args.steps * 1e3
+        for G in (2, 4, 8):
+            e = acq_by_m.get(str(M_CAND // G))
+            if e:
+                ms = ms_u + e["first_call_ms"] + 0.03
+                strong.setdefault("predicted_from_single_gpu", {})[f"G={G}"] = {
+                    "ms_per_step": ms, "acq_evals_per_sec": M_CAND / (e["first_call_ms"] + 0.03) * 1e3, "steps_per_sec": 1e3 / ms,
+                    "speedup_of_the_step_over_G=1": (s_elapsed / args.steps * 1e3) / ms,
+                    "note": "replicated update (not sharded: 'replicas only') + first acquisition call of M/G candidates + 16-byte exchange"}
+
     if rank == 0:
         upd_rate = world * args.steps / t_upd
         acq_rate = world * args.steps * M_CAND / t_acq
