@@ -738,6 +738,8 @@ def main():
                                            "acq": flops_acq_eval(N_OBS, D) * acq_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12)},
             "roofline": roof, "roofline_potrf": roof_potrf, "update_latency": upd_dist, "strong_scaling": strong, "strong_scaling_inproc": inproc,
             "batched_updates": batched, "acq_by_M": acq_by_m, "cpu_baseline": cpu, "next_rows": extras,
+            # BASELINE config 5 end to end (also inside batched_updates, next to the bare batched likelihood it is compared with)
+            "config5_acq_S512": (batched or {}).get("config5_acq_S512"),
         }
         if os.environ.get("BOSS_BENCH_REHEARSAL"):
             out["rehearsal"] = f"{world} ranks share {n_vis} GPU(s), exchange over gloo — a functional rehearsal of the N>1 path, not a scaling measurement"
