@@ -22,6 +22,7 @@
 #include "gp_kernels.hpp"
 #include "potrf.hpp"
 #include "chain.hpp"
+#include "small_calls.hpp"
 
 using namespace boss;
 
@@ -101,6 +102,8 @@ struct Ctx {
     bool test_drop_chain = false;              // BOSS_TEST_DROP_CHAIN=1: the chain kernel is never launched (exercises the fallback)
     unsigned long long acq_seq = 0;            // sequence number of the arg-max result block (boss_acq_ei polls it)
     unsigned long long few_seq = 0;            // ... of the few-candidates prediction's result block (boss_gp_predict)
+    unsigned long long* few_done = nullptr;    // device counter of finished workgroups (winv_args_kernel) and its value on the host
+    unsigned long long few_done_cnt = 0;
     bool lookahead = true;
     bool prof_on = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;
@@ -135,6 +138,7 @@ static void ctx_destroy(Ctx* c) {
     if (c->strip_stream) (void)hipStreamDestroy(c->strip_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->sig_panel) (void)hipFree(c->sig_panel);
+    if (c->few_done) (void)hipFree(c->few_done);
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     for (int i = 0; i < Ctx::LLG_BANKS - 1; ++i) {
         if (c->llg_stream[i]) (void)hipStreamDestroy(c->llg_stream[i]);
@@ -251,6 +255,10 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)winv_gemv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)winv_args_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)winv_args_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)winv_args_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)winv_args_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)few_back_finish_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)few_w_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize, PredictLds<PredG32>::BYTES));
@@ -469,6 +477,24 @@ extern "C" int boss_device_sync(int device) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return BOSS_OK;
+}
+
+// the device counter of winv_args_kernel (small_calls.hpp): allocated on first use; false = not available (the callers keep their
+// multi-launch paths)
+static bool few_done_ensure(Ctx* c, hipStream_t s) {
+    if (c->few_done) return true;
+    if (hipMalloc((void**)&c->few_done, sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        c->few_done = nullptr;
+        return false;
+    }
+    (void)hipMemsetAsync(c->few_done, 0, sizeof(unsigned long long), s);
+    c->few_done_cnt = 0;
+    return true;
+}
+static bool few_fused() {
+    static const bool v = !(getenv("BOSS_FEW_FUSED") && atoi(getenv("BOSS_FEW_FUSED")) == 0);
+    return v;
 }
 
 #include "host_factor.inc"

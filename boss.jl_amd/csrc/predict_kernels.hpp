@@ -920,7 +920,7 @@ __global__ __launch_bounds__(64) void append_point_kernel(AppendPoint par, doubl
     if (k == 0) {
         y[par.N0] = par.y;
         mean[par.N0] = par.mean;
-        *info = 0;
+        if (info) *info = 0;                                 // (null: the fused append pass in front of this kernel has already set it)
     }
 }
 
@@ -986,7 +986,7 @@ struct FewCand {
     double mean[WINV_MAX_M];                                 // prior mean at the candidates
 };
 __global__ __launch_bounds__(256) void kstar_args_kernel(FewCand par, const double* __restrict__ Xsc, int Np, int N, int d, int kern,
-                                                         double amp2, double* __restrict__ kst) {
+                                                         double amp2, double* __restrict__ kst, int stride = 32) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     double r2[WINV_MAX_M];
 #pragma unroll
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void kstar_args_kernel(FewCand par, const doub
     const bool live = row < N;
 #pragma unroll
     for (int c = 0; c < WINV_MAX_M; ++c)
-        if (c < par.ncols) kst[(size_t)row * 32 + c] = live ? amp2 * kappa_r2(kern, r2[c]) : 0.0;
+        if (c < par.ncols) kst[(size_t)row * stride + c] = live ? amp2 * kappa_r2(kern, r2[c]) : 0.0;
 }
 // host_out (mapped host memory): [0..4) μ, [4..8) σ² (clipped), [8] first index whose variance is below -1e-8 (or -1), [9] sequence number
 __global__ __launch_bounds__(256) void winv_finish_host_kernel(const double* __restrict__ part, int nwg, FewCand par, double amp2,

@@ -1358,6 +1358,53 @@ def test_repeated_few_candidate_calls_use_the_explicit_inverse(api, O, N, M):
     g.close()
 
 
+def test_one_launch_small_calls_interleaved_on_two_handles():
+    """One to four candidates and rank-one appends on resident inverse factors run as ONE launch whose last workgroup reduces the
+    partials and answers through mapped host memory (csrc/small_calls.hpp); the finished-workgroup counter and the partial buffer
+    belong to the device context, i.e. two handles share them.  200 interleaved calls on two posteriors of different sizes give,
+    bit for bit, what the three-launch path gives (BOSS_FEW_FUSED=0: same sums in the same order) — and both agree with the oracle."""
+    import subprocess
+    import sys
+    entry.build()
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from boss_jl_amd import api
+from oracle import gp_oracle as O
+api.load_library()
+rng = np.random.default_rng(77); d = 4
+hs, data = [], []
+for N in (700, 1500):
+    X = rng.uniform(0, 1, (d, N)); y = np.cos(3 * X).sum(0) / 2 + 0.05 * rng.standard_normal(N)
+    g = api.GP(X, y, "matern52"); g.reserve(N + 40); g.update(np.full(d, 0.45), 1.2, 0.06)
+    g.predict(rng.uniform(0, 1, (d, 1))); g.predict(rng.uniform(0, 1, (d, 1)))      # the second call builds the inverse factors
+    hs.append(g); data.append([X, y])
+out = []
+for it in range(200):
+    h = it %% 2; g = hs[h]
+    if it %% 10 == 9:
+        xn = rng.uniform(0, 1, (d, 1)); yn = float(rng.standard_normal() * 0.1)
+        out.append(g.append(xn, [yn]))
+        data[h][0] = np.hstack([data[h][0], xn]); data[h][1] = np.append(data[h][1], yn)
+    else:
+        M = 1 + it %% 4
+        Xs = rng.uniform(0, 1, (d, M))
+        mu, var = g.predict(Xs)
+        out += list(mu) + list(var)
+        if it %% 37 == 0:
+            post = O.gp_fit(data[h][0], data[h][1], "matern52", np.full(d, 0.45), 1.2, 0.06)
+            mo, vo = O.gp_mean_and_var(post, Xs)
+            assert np.allclose(mu, mo, rtol=0, atol=1e-9) and np.allclose(var, vo, rtol=0, atol=1e-9), it
+print("RES", " ".join(float(v).hex() for v in out))
+""" % ROOT
+    res = {}
+    for tag, extra in (("one launch", {}), ("three launches", {"BOSS_FEW_FUSED": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "RES" in r.stdout, tag + ": " + r.stdout[-2000:] + r.stderr[-2000:]
+        res[tag] = r.stdout.split("RES")[1].split()
+    assert len(res["one launch"]) > 400 and res["one launch"] == res["three launches"]
+
+
 def test_repeated_single_candidate_calls_on_gradient_and_nonstationary_posteriors(api, O):
     d, n = 3, 300                                            # 1200 augmented rows
     X, y, dY = make_grad(d, n)
