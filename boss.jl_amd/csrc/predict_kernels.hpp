@@ -636,6 +636,46 @@ __global__ __launch_bounds__(G::NTHREADS) void few_finish_kernel(const double* _
 constexpr int WINV_ROWS = 8;                                  // rows k per workgroup (two per wave)
 constexpr int WINV_MAX_M = WINV_MAX_M_DECL;
 constexpr int FEW_ARGS_MAX_D = 16;                          // x_dim up to which few candidates / one appended point travel in kernel arguments
+// The walk of one wave over its two rows k0, k0+1 (columns of U, contiguous in c; row k0 ends at c = k0, row k0+1 at c = k0+1):
+// a0[j] += Σ_c U[c, k0] k*_c[j], a1 likewise — per lane, to be summed over the wave by the caller.  16-byte loads, four 128-element
+// chunks of both rows in flight per lane.  Shared by winv_gemv_kernel and winv_args_kernel (small_calls.hpp): same sums in the
+// same order.  (Measured and not kept: all four waves of a workgroup sharing the column range of its eight rows — 23 against
+// 22 µs per pass; the pass is not bound by its longest wave.)
+template <int MC>
+__device__ __forceinline__ void winv_walk(const double* __restrict__ col0, const double* __restrict__ col1, const double* __restrict__ ks,
+                                          int k0, int lane, double (&a0)[MC], double (&a1)[MC]) {
+    int base = 0;
+    for (; base + 512 <= k0 + 1; base += 512) {              // every element of both rows in [base, base + 512) is inside the triangle
+        v2d u0[4], u1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + 128 * u + 2 * lane;
+            u0[u] = *reinterpret_cast<const v2d*>(col0 + c);
+            u1[u] = *reinterpret_cast<const v2d*>(col1 + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + 128 * u + 2 * lane;
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                const double q0 = ks[c * MC + j], q1 = ks[(c + 1) * MC + j];
+                a0[j] = __builtin_fma(u0[u][0], q0, a0[j]);
+                a1[j] = __builtin_fma(u1[u][0], q0, a1[j]);
+                a0[j] = __builtin_fma(u0[u][1], q1, a0[j]);
+                a1[j] = __builtin_fma(u1[u][1], q1, a1[j]);
+            }
+        }
+    }
+    for (int c = base + lane; c <= k0 + 1; c += 64) {         // the rest, element by element (row k0 stops one entry before row k0+1)
+        const double u0 = (c <= k0) ? col0[c] : 0.0, u1 = col1[c];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            const double q = ks[c * MC + j];
+            a0[j] = __builtin_fma(u0, q, a0[j]);
+            a1[j] = __builtin_fma(u1, q, a1[j]);
+        }
+    }
+}
 template <int MC>                                            // candidates staged per call: 1, 2 or 4
 __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict__ U, int ldu, int Np,
                                                         const double* __restrict__ Afac, int ld,
@@ -656,27 +696,7 @@ __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict
     double a0[MC], a1[MC];
 #pragma unroll
     for (int j = 0; j < MC; ++j) a0[j] = a1[j] = 0.0;
-    int c = lane;
-    for (; c + 64 <= k0; c += 128) {                         // two 64-wide chunks per trip: four loads in flight per lane
-        const double u00 = col0[c], u10 = col1[c], u01 = col0[c + 64], u11 = col1[c + 64];
-#pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            const double q0 = ks[c * MC + j], q1 = ks[(c + 64) * MC + j];
-            a0[j] = __builtin_fma(u00, q0, a0[j]);
-            a1[j] = __builtin_fma(u10, q0, a1[j]);
-            a0[j] = __builtin_fma(u01, q1, a0[j]);
-            a1[j] = __builtin_fma(u11, q1, a1[j]);
-        }
-    }
-    for (; c <= k0 + 1; c += 64) {                           // the ragged end (row k0 stops one entry before row k0+1)
-        const double u0 = (c <= k0) ? col0[c] : 0.0, u1 = col1[c];
-#pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            const double q = ks[c * MC + j];
-            a0[j] = __builtin_fma(u0, q, a0[j]);
-            a1[j] = __builtin_fma(u1, q, a1[j]);
-        }
-    }
+    winv_walk<MC>(col0, col1, ks, k0, lane, a0, a1);
     const double z0 = Afac[(size_t)k0 * ld + Np], z1 = Afac[(size_t)(k0 + 1) * ld + Np];
     double ss[MC], mz[MC];
 #pragma unroll
@@ -843,10 +863,35 @@ __global__ __launch_bounds__(256) void linv_col_gemv_kernel(const double* __rest
     const double* col1 = col0 + ldl;
     const bool two = c0 + 1 < N0;
     double a0 = 0.0, a1 = 0.0;
-    for (int r = c0 + lane; r < N0; r += 64) {
+    int base = c0;                                           // (even: 16-byte aligned)
+    if (two) {
+        if (lane == 0) {                                     // rows c0, c0+1 by hand: entry (c0, c0+1) lies above the diagonal
+            a0 = col0[c0] * l[c0] + col0[c0 + 1] * l[c0 + 1];
+            a1 = col1[c0 + 1] * l[c0 + 1];
+        }
+        base = c0 + 2;
+        for (; base + 512 <= N0; base += 512) {              // 16-byte loads, four chunks of both columns in flight per lane: 25 -> 14 µs per pass
+            v2d u0[4], u1[4], lr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = base + 128 * u + 2 * lane;
+                u0[u] = *reinterpret_cast<const v2d*>(col0 + r);
+                u1[u] = *reinterpret_cast<const v2d*>(col1 + r);
+                lr[u] = *reinterpret_cast<const v2d*>(l + r);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0 = __builtin_fma(u0[u][0], lr[u][0], a0);
+                a1 = __builtin_fma(u1[u][0], lr[u][0], a1);
+                a0 = __builtin_fma(u0[u][1], lr[u][1], a0);
+                a1 = __builtin_fma(u1[u][1], lr[u][1], a1);
+            }
+        }
+    }
+    for (int r = base + lane; r < N0; r += 64) {
         const double lr = l[r];
         a0 = __builtin_fma(col0[r], lr, a0);
-        if (two && r > c0) a1 = __builtin_fma(col1[r], lr, a1);
+        if (two) a1 = __builtin_fma(col1[r], lr, a1);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

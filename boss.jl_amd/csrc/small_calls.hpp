@@ -35,12 +35,13 @@ __global__ __launch_bounds__(256) void winv_args_kernel(FewCand par, const doubl
     const int kb = (gridDim.x - 1 - blockIdx.x) * WINV_ROWS;  // longest rows first
     // K* for the rows this workgroup's dot products reach (c <= kb + WINV_ROWS - 1): eight rows per thread and trip, all their
     // coordinate loads in flight together (one row at a time left the longest workgroup 16 dependent L2 round trips behind)
-    // kst (or null): K* [c][MC] already evaluated by kstar_args_kernel — for ONE candidate that launch (one row per thread across
+    // kst (or null): K* [c][MC] already evaluated by kstar_args_kernel (the host passes it for ONE candidate only) — for ONE candidate that launch (one row per thread across
     // the chip) costs less than the 16 evaluations per thread the longest workgroup would do here; for two and four it does not
     constexpr int KU = 8;
     const int cend = kb + WINV_ROWS;
     if (kst) {
-        for (int idx = tid; idx < cend * MC; idx += 256) ks[idx] = kst[idx];
+        // nothing to stage: the walk below reads K* from global memory (32 KB, L2-resident) beside the two rows of U — no staging loop,
+        // no barrier in front of the first load of U (the staged form of the same pass: 22 against 14 µs)
     } else
     for (int c0 = tid; c0 < cend; c0 += 256 * KU) {
         double r2[KU][MC];
@@ -75,27 +76,8 @@ __global__ __launch_bounds__(256) void winv_args_kernel(FewCand par, const doubl
     double a0[MC], a1[MC];
 #pragma unroll
     for (int j = 0; j < MC; ++j) a0[j] = a1[j] = 0.0;
-    int c = lane;
-    for (; c + 64 <= k0; c += 128) {
-        const double u00 = col0[c], u10 = col1[c], u01 = col0[c + 64], u11 = col1[c + 64];
-#pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            const double q0 = ks[c * MC + j], q1 = ks[(c + 64) * MC + j];
-            a0[j] = __builtin_fma(u00, q0, a0[j]);
-            a1[j] = __builtin_fma(u10, q0, a1[j]);
-            a0[j] = __builtin_fma(u01, q1, a0[j]);
-            a1[j] = __builtin_fma(u11, q1, a1[j]);
-        }
-    }
-    for (; c <= k0 + 1; c += 64) {
-        const double u0 = (c <= k0) ? col0[c] : 0.0, u1 = col1[c];
-#pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            const double q = ks[c * MC + j];
-            a0[j] = __builtin_fma(u0, q, a0[j]);
-            a1[j] = __builtin_fma(u1, q, a1[j]);
-        }
-    }
+    if (kst) winv_walk<MC>(col0, col1, kst, k0, lane, a0, a1);
+    else winv_walk<MC>(col0, col1, ks, k0, lane, a0, a1);
     const double z0 = Afac[(size_t)k0 * ld + Np], z1 = Afac[(size_t)(k0 + 1) * ld + Np];
     double ss[MC], mz[MC];
 #pragma unroll
