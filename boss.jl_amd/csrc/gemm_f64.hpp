@@ -238,7 +238,25 @@ struct GemmDirect {
         return wc * (TN * 16) + (n >> 1) * 32 + 2 * ((lane >> 4) + 4 * i) + (n & 1);
     }
 
-    template <int SIGN>
+    // slot S of a ring that is no longer refilled: wait until slots 0 .. S have landed (loads complete in order), consume it, go on
+    template <int SIGN, int S>
+    __device__ static __forceinline__ void ring_tail(v2d (&af)[D][PM], v2d (&bf)[D][PN], v4d (&acc)[TM][TN]) {
+        if constexpr (S < D) {
+            wait_vmcnt<(PM + PN) * (D - 1 - S)>();
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    const double b = bf[S][t >> 1][t & 1];
+                    acc[m][t] = mfma_f64(SIGN < 0 ? -b : b, af[S][m >> 1][m & 1], acc[m][t]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            ring_tail<SIGN, S + 1>(af, bf, acc);
+        }
+    }
+
+    // EXACT: the caller guarantees that K/4 is a multiple of D (and >= D): see the ring tail below
+    template <int SIGN, bool EXACT = false>
     __device__ static __forceinline__ void run(const double* __restrict__ A, int lda, const double* __restrict__ B,
                                                int ldb, int K, v4d (&acc)[TM][TN]) {
         const int lane = threadIdx.x & 63;
@@ -278,7 +296,11 @@ struct GemmDirect {
         // (PM+PN)(D-1) younger ring loads are in flight (every pass re-issues every slot, clamped).
         // Row pair p's A fragment is re-loaded right after the MFMAs that read it, so the load issue
         // sits in the shadow of the next pair's MFMAs; the B fragments go last (every MFMA reads them).
-        const int npass = n / D;
+        // EXACT — n a multiple of D (short K: 128 … 512 with D = 4, 8, 16; the trailing updates of potrf.hpp): the last D substeps are consumed AS THEY LAND — one pass less in the
+        // loop (whose reloads would all be clamped duplicates of the last slice: a quarter of the loads at K = 128, D = 8), then a sweep
+        // over the ring with the wait count falling by one slot per substep instead of a full drain in front of the remainder.
+        constexpr bool exact = EXACT;
+        const int npass = exact ? n / D - 1 : n / D;
         for (int g = 0; g < npass; ++g) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -305,6 +327,10 @@ struct GemmDirect {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        }
+        if constexpr (exact) {
+            ring_tail<SIGN, 0>(af, bf, acc);
+            return;
         }
         wait_vmcnt<0>();                        // ring drained: the (clamped) reloads of the last pass
         const int rem = n - npass * D;          // < D k-substeps left; their operands are already in the ring

@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(64) void potrf_dinv_kernel(const double* __restrict
 // right-hand-side row block (i == m, only its first 32 rows are live).
 // ------------------------------------------------------------------------------------------
 #ifndef BOSS_RHS_D
-#define BOSS_RHS_D 12     // ring depth of the strip GEMM: K is short (128–256), the loop is bound by the distance between a fragment load and its use (4: 1.489, 8: 1.477, 12: 1.470, 16: 1.475 ms per N=4096 update)
+#define BOSS_RHS_D 4      // ring depth of the strip GEMM.  It must DIVIDE the 32 k-substeps of a K = 128 strip: the ring's tail is then exact (gemm_f64.hpp: the last D substeps are consumed as they land — no clamped reloads, no full drain in front of a remainder).  ms per N = 4096 update with the exact tail, round 4: D = 2: 1.199, 4: 1.135–1.142, 8: 1.140–1.143, 16: 1.248; D = 12 (round 3's depth, drained tail): 1.161
 #endif
 typedef GemmDirect<2, 2, 4, 4, 4> SyrkG;   // 128×128 tile, fragments streamed from L2, no LDS
 typedef GemmDirect<1, 4, 2, 2, BOSS_RHS_D> RhsG;    // 32×128 tile for the δ^T row block and the column updates
@@ -1291,7 +1291,7 @@ __device__ __forceinline__ void syrk_tile(double* __restrict__ A, int ld, int k,
                 acc[m][n][i] = c2[0];
                 acc[m + 1][n][i] = c2[1];
             }
-    G::template run<-1>(Pi, ld, Pj, ld, K, acc);
+    G::template run<-1, (BLK / 4) % G::D == 0>(Pi, ld, Pj, ld, K, acc);   // (K is a multiple of BLK: exact ring tail where D divides 32)
 #pragma unroll
     for (int m = 0; m < G::TM; m += 2)
 #pragma unroll
