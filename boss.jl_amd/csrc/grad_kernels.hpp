@@ -170,7 +170,7 @@ __global__ __launch_bounds__(GU::NTHREADS) void few_back_update_kernel(const dou
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[m][n][i] = Rb[row * 32 + GU::col_of(0, n, i, lane)];
     }
-    GU::template run<-1>(LT + (size_t)r0 + (size_t)ib * PRED_RB * ldt, ldt, V + (size_t)ib * PRED_RB * 32, 32, PRED_RB, acc);
+    GU::template run<-1, (PRED_RB / 4) % GU::D == 0>(LT + (size_t)r0 + (size_t)ib * PRED_RB * ldt, ldt, V + (size_t)ib * PRED_RB * 32, 32, PRED_RB, acc);
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
         const int row = GU::row_of(wave, m, lane);

@@ -346,7 +346,7 @@ __device__ __forceinline__ void few_update_body(const double* __restrict__ A, in
             acc[m][1][i] = v[1];
         }
     }
-    GU::template run<-1>(A + (size_t)r0 + (size_t)isrc * PRED_RB * ld, ld, V + (size_t)isrc * PRED_RB * 32, 32, K, acc);
+    GU::template run<-1, (PRED_RB / 4) % GU::D == 0>(A + (size_t)r0 + (size_t)isrc * PRED_RB * ld, ld, V + (size_t)isrc * PRED_RB * 32, 32, K, acc);   // (K = 256 or 512: exact ring tail)
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
         const int row = GU::row_of(wave, m, lane);
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(GU::NTHREADS) void inv_fwd_kernel(const double* __r
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-    GU::template run<1>(Linv + r0, ldl, B, 32, r0 + BM, acc);
+    GU::template run<1, (BLK / 4) % GU::D == 0>(Linv + r0, ldl, B, 32, r0 + BM, acc);   // (K a multiple of 128: exact ring tail)
     double ps[TN][4], pz[TN][4];
 #pragma unroll
     for (int n = 0; n < TN; ++n)
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(GU::NTHREADS) void inv_bwd_kernel(const double* __r
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-    GU::template run<1>(Uinv + r0 + (size_t)r0 * ldu, ldu, V + (size_t)r0 * 32, 32, Np - r0, acc);
+    GU::template run<1, (BLK / 4) % GU::D == 0>(Uinv + r0 + (size_t)r0 * ldu, ldu, V + (size_t)r0 * 32, 32, Np - r0, acc);
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
         const int row = r0 + GU::row_of(wave, m, lane);
