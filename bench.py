@@ -521,6 +521,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         note("next rows (gradients, appends, small sizes, gradient observations)")
         gp.update(lam, 1.0, 0.05)
+        gp.predict_grad(Xs)                                          # first gradient call on a handle: lazy allocations (transposed factor, 138 MB)
+        gp.update(lam, 1.0, 0.05)
         t0 = time.perf_counter()
         for _ in range(3):
             gp.predict_grad(Xs)

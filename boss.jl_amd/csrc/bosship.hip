@@ -102,6 +102,13 @@ struct Ctx {
     bool test_drop_chain = false;              // BOSS_TEST_DROP_CHAIN=1: the chain kernel is never launched (exercises the fallback)
     unsigned long long acq_seq = 0;            // sequence number of the arg-max result block (boss_acq_ei polls it)
     unsigned long long few_seq = 0;            // ... of the few-candidates prediction's result block (boss_gp_predict)
+    // one released slab / pinned block of a batch-fitted set (boss_gp_fit_batch), kept for the next fit of that size: a BI fitter calls it
+    // once per BO iteration with the same S and N, and hipMalloc / hipFree of 4.5 GB took 0.2 s on some boxes (3 ms on others)
+    std::mutex slab_mtx;
+    void* slab_cache = nullptr;
+    size_t slab_cache_bytes = 0;
+    void* hostblk_cache = nullptr;
+    size_t hostblk_cache_bytes = 0;
     unsigned long long* few_done = nullptr;    // device counter of finished workgroups (winv_args_kernel) and its value on the host
     unsigned long long few_done_cnt = 0;
     bool lookahead = true;
@@ -139,6 +146,8 @@ static void ctx_destroy(Ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->sig_panel) (void)hipFree(c->sig_panel);
     if (c->few_done) (void)hipFree(c->few_done);
+    if (c->slab_cache) (void)hipFree(c->slab_cache);
+    if (c->hostblk_cache) (void)hipHostFree(c->hostblk_cache);
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     for (int i = 0; i < Ctx::LLG_BANKS - 1; ++i) {
         if (c->llg_stream[i]) (void)hipStreamDestroy(c->llg_stream[i]);
@@ -365,7 +374,32 @@ struct boss_gpset {
     std::atomic<int> refs{0};
     void* slab = nullptr;
     void* host_block = nullptr;
+    size_t slab_bytes = 0, host_bytes = 0;
 };
+static bool slab_cache_on() {
+    static const bool v = !(getenv("BOSS_SLAB_CACHE") && atoi(getenv("BOSS_SLAB_CACHE")) == 0) &&
+                          !(getenv("BOSS_POISON_ALLOC") && atoi(getenv("BOSS_POISON_ALLOC")));   // (poisoned allocations are for finding reads of never-written memory: always fresh)
+    return v;
+}
+// the last member of a set is gone: its storage goes to the context's one-entry cache (the larger block wins) or back to the device
+static void gpset_release_storage(boss_gpset* st) {
+    Ctx* c = st->ctx;
+    void *slab = st->slab, *hb = st->host_block;
+    if (c && slab_cache_on()) {
+        std::lock_guard<std::mutex> lk(c->slab_mtx);
+        if (slab && st->slab_bytes > c->slab_cache_bytes) {
+            std::swap(slab, c->slab_cache);
+            c->slab_cache_bytes = st->slab_bytes;
+        }
+        if (hb && st->host_bytes > c->hostblk_cache_bytes) {
+            std::swap(hb, c->hostblk_cache);
+            c->hostblk_cache_bytes = st->host_bytes;
+        }
+    }
+    if (slab) (void)hipFree(slab);
+    if (hb) (void)hipHostFree(hb);
+    st->slab = st->host_block = nullptr;
+}
 
 struct boss_gp {
     Ctx* ctx = nullptr;
