@@ -225,3 +225,35 @@ def test_config5_all_512_posteriors_resident(api, O):
     assert np.allclose(mus, want_mu, rtol=0, atol=1e-9 * (1 + np.abs(want_mu).max()))
     for g in gps:
         g.close()
+
+
+def test_released_storage_is_reused_without_leaking_into_the_next_set(api, O):
+    """The storage of a set whose last member is gone stays with the device context for the next boss_gp_fit_batch (a BI fitter refits
+    its samples every iteration).  A larger set, then a smaller one in the block the larger one left behind, then a larger one again
+    (the cached block is too small: fresh storage), with a member kept alive across the hand-over: every posterior agrees with the
+    oracle, i.e. nothing of the previous tenant's factors, inverses or scalars is read."""
+    shapes = [(4, 700, 6), (3, 300, 3), (2, 140, 5), (4, 900, 7), (3, 300, 3)]
+    keep = None
+    for rnd, (d, N, S) in enumerate(shapes):
+        X, y, Xs = make(d, N, 40, seed=100 + rnd)
+        lam, amp, sig = draw(d, S, 200 + rnd)
+        gps, ll, st = api.fit_batch(X, y, "matern52", lam, amp, sig)
+        assert np.all(st == api.BOSS_OK)
+        for s in range(S):
+            post = O.gp_fit(X, y, "matern52", lam[:, s], amp[s], sig[s])
+            assert abs(ll[s] - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf)), (rnd, s)
+            mu, var = gps[s].predict(Xs)
+            mu_o, var_o = O.gp_mean_and_var(post, Xs)
+            assert np.allclose(mu, mu_o, rtol=0, atol=1e-9 * (1 + np.abs(mu_o).max())), (rnd, s)
+            assert np.allclose(var, var_o, rtol=0, atol=1e-9 * amp[s] ** 2), (rnd, s)
+        if keep is not None:
+            # the survivor of the previous round still describes ITS data (its set's block cannot have been handed on)
+            g_old, post_old, Xs_old = keep
+            mu, var = g_old.predict(Xs_old)
+            mu_o, var_o = O.gp_mean_and_var(post_old, Xs_old)
+            assert np.allclose(mu, mu_o, rtol=0, atol=1e-9 * (1 + np.abs(mu_o).max())) and np.allclose(var, var_o, rtol=0, atol=1e-9 * 4), rnd
+            g_old.close()
+        keep = (gps[0], O.gp_fit(X, y, "matern52", lam[:, 0], amp[0], sig[0]), Xs)
+        for g in gps[1:]:
+            g.close()
+    keep[0].close()
