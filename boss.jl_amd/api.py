@@ -62,6 +62,9 @@ SIGNATURES = {
     "boss_cand_free": (None, [C.c_void_p]),
     "boss_acq_ei": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, _c_dp, _c_dp, _c_dp, C.c_int,
                               C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_gp_update_acq": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, _c_dp, C.c_void_p, _c_dp, C.c_double, C.c_double,
+                                     C.c_int, C.c_double, _c_ucp, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long), _c_dp,
+                                     C.POINTER(C.c_int)]),
     "boss_acq_ei_moments": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
                                       C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
     "boss_acq_ei_grad": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
@@ -214,6 +217,36 @@ class GP:
             self.logpdf = out.value
             return out.value
         return None
+
+    def update_acq(self, lengthscale, amplitude, noise_std, cand: "Candidates", fit_coef: float = 1.0, y_max: float = np.inf,
+                   best=None, mean_X=None, mean_Xs=None, valid_mask=None, want_acq: bool = False, want_moments: bool = False):
+        """One BO iteration's posterior update with its first acquisition riding along the factorisation
+        (boss_gp_update_acq): `update` followed by `acq_ei([[self]], cand, [fit_coef], [y_max], best)` in one call.
+        Returns a dict: logpdf, argmax, max, fused (True when the substitution rode along), and acq / mu / var on request
+        (mu, var unclipped)."""
+        lam = _f64(np.asarray(lengthscale).reshape(-1), 1)
+        if lam.shape[0] != self.d:
+            raise BossError(BOSS_E_INVALID, "length(lengthscales) must equal x_dim")
+        m = None if mean_X is None else _f64(np.asarray(mean_X).reshape(-1), 1)
+        if m is not None and m.shape[0] != self.N:
+            raise ValueError("mean_X must have N entries")
+        M = cand.M
+        ms = None if mean_Xs is None else _f64(np.asarray(mean_Xs).reshape(-1), 1)
+        if ms is not None and ms.shape[0] != M:
+            raise ValueError("mean_Xs must have one entry per candidate")
+        mask = None if valid_mask is None else np.ascontiguousarray(np.asarray(valid_mask, dtype=bool).astype(np.uint8))
+        if mask is not None and mask.shape[0] != M:
+            raise ValueError("valid_mask must have one entry per candidate")
+        acq = np.zeros(M) if want_acq else None
+        mu = np.zeros(M) if want_moments else None
+        var = np.zeros(M) if want_moments else None
+        lp, am, mx, fused = C.c_double(0.0), C.c_long(-1), C.c_double(0.0), C.c_int(0)
+        _check(load_library().boss_gp_update_acq(self._h, _dp(lam), float(amplitude), float(noise_std), _dp(m), cand._h, _dp(ms),
+                                                 float(fit_coef), float(y_max), 0 if best is None else 1,
+                                                 0.0 if best is None else float(best), _ucp(mask), C.byref(lp), _dp(mu), _dp(var),
+                                                 _dp(acq), C.byref(am), C.byref(mx), C.byref(fused)))
+        self.logpdf = lp.value
+        return {"logpdf": lp.value, "argmax": am.value, "max": mx.value, "fused": bool(fused.value), "acq": acq, "mu": mu, "var": var}
 
     def sync(self) -> float:
         out = C.c_double(0.0)

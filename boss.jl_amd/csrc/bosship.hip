@@ -23,6 +23,7 @@
 #include "potrf.hpp"
 #include "chain.hpp"
 #include "small_calls.hpp"
+#include "rider.hpp"
 
 using namespace boss;
 
@@ -419,6 +420,7 @@ struct boss_gp {
     bool dinv_used_prev = false;               // its value when the pending update was enqueued (restored if that update is repeated)
     bool gated = false;                        // the pending update was enqueued with gate kernels
     bool chained = false;                      // ... and under the resident panel chain (chain.hpp)
+    bool fell_back = false;                    // gp_finish repeated the pending update on a simpler schedule
     double* host_res = nullptr;                // pinned: scal[2], info
     double* host_res_dev = nullptr;            // the same memory through its device address (written by small_fit_kernel / potrf_logdet_kernel)
     bool par_in_args = false;                  // this update's hyper-parameters travel in the first kernel's arguments
@@ -536,6 +538,7 @@ static bool few_fused() {
 #include "host_batch.inc"
 #include "host_predict.inc"
 #include "host_acq.inc"
+#include "host_rider.inc"
 #include "host_track.inc"
 #include "host_multi.inc"
 
@@ -642,6 +645,19 @@ extern "C" int boss_debug_ctrace(unsigned long long* chain /*64*16*/, unsigned l
         }
         (void)hipMemcpyToSymbol(HIP_SYMBOL(boss::g_ctrace), a, sizeof a);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(boss::g_cutrace), b, sizeof b);
+    }
+    return 0;
+}
+extern "C" int boss_debug_rtrace(unsigned long long* rider /*64*4*/, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (rider && hipMemcpyFromSymbol(rider, HIP_SYMBOL(boss::g_rtrace), sizeof(unsigned long long) * 64 * 4) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long a[64 * 4];
+        for (int i = 0; i < 64; ++i) {
+            a[i * 4 + 0] = ~0ull;
+            a[i * 4 + 1] = a[i * 4 + 2] = a[i * 4 + 3] = 0;
+        }
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(boss::g_rtrace), a, sizeof a);
     }
     return 0;
 }

@@ -266,6 +266,27 @@ int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_t* cand,
                 int has_best, double best, const unsigned char* valid_mask,
                 double* acq_out, long* argmax_out, double* max_out);
 
+/* One BO iteration's model update AND its first acquisition in one call: the candidates' forward substitution rides along
+ * the factorisation (csrc/rider.hpp) instead of starting when it has ended.
+ * Replaces: the pair `estimate_parameters!` -> `maximize_acquisition` of src/bo.jl:30-48 for maximisers whose candidates
+ * do not depend on the posterior (SamplingAM, src/acquisition_maximizers/sampling.jl:43-57; GridAM, grid.jl:52-65) —
+ * i.e. boss_gp_update (posterior_gp, src/models/gaussian_process.jl:199-211) followed by boss_acq_ei (P = 1, S = 1:
+ * mean_and_var :174-178 + construct_ei, src/acquisitions/expected_improvement.jl:68-101) on the SAME handle.
+ *   gp, lengthscale, amplitude, noise_std, mean_X: as boss_gp_update;   cand: resident candidates on gp's device;
+ *   mean_Xs  NULL or M prior means at the candidates;   fit_coef: the LinFitness coefficient of this output;
+ *   y_max    the output's upper constraint, +Inf = unconstrained;   has_best / best, valid_mask: as boss_acq_ei;
+ *   logpdf_out  the update's log marginal likelihood;   mu_out / var_out  M posterior moments (unclipped: what
+ *       mean_and_var returns before _clip_var; the EI epilogue clips) or NULL;   acq_out  M values or NULL;
+ *   argmax_out / max_out as boss_acq_ei;   fused_out (or NULL): 1 = the substitution rode along, 0 = the call ran the two
+ *       phases one after the other (no resident chain for this size / device / stream, N <= 128, x_dim > 32, a fallback).
+ * The numbers do not depend on which way the call went beyond the stated fp64 tolerance (the order of the floating-point
+ * sums differs); repeated calls on one path are bit-identical.  Errors: as boss_gp_update (BOSS_E_NOT_PD leaves the handle
+ * unfitted and the acquisition outputs untouched). */
+int boss_gp_update_acq(boss_gp_t* gp, const double* lengthscale, double amplitude, double noise_std, const double* mean_X,
+                       const boss_cand_t* cand, const double* mean_Xs, double fit_coef, double y_max, int has_best,
+                       double best, const unsigned char* valid_mask, double* logpdf_out, double* mu_out, double* var_out,
+                       double* acq_out, long* argmax_out, double* max_out, int* fused_out);
+
 /* The same EI x feasibility epilogue (expected_improvement.jl:68-101,113-114) and arg-max, but
  * from posterior moments the caller already holds: mu/var are S×P×M, index j + M*(p + P*s)
  * (row p of sample s is what mean_and_var(post_s, Xs)[p, :] returns, src/posterior.jl:60-72).
