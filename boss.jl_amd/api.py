@@ -218,10 +218,11 @@ class GP:
             return out.value
         return None
 
-    def update_acq(self, lengthscale, amplitude, noise_std, cand: "Candidates", fit_coef: float = 1.0, y_max: float = np.inf,
+    def update_acq(self, lengthscale, amplitude, noise_std, cand: "Candidates", fit_coef: float = 1.0, y_max: Optional[float] = None,
                    best=None, mean_X=None, mean_Xs=None, valid_mask=None, want_acq: bool = False, want_moments: bool = False):
         """One BO iteration's posterior update with its first acquisition riding along the factorisation
-        (boss_gp_update_acq): `update` followed by `acq_ei([[self]], cand, [fit_coef], [y_max], best)` in one call.
+        (boss_gp_update_acq): `update` followed by `acq_ei([[self]], cand, [fit_coef], [y_max], best)` in one call
+        (y_max None: `constraints === nothing`; +Inf: a constraint that always holds).
         Returns a dict: logpdf, argmax, max, fused (True when the substitution rode along), and acq / mu / var on request
         (mu, var unclipped)."""
         lam = _f64(np.asarray(lengthscale).reshape(-1), 1)
@@ -242,7 +243,7 @@ class GP:
         var = np.zeros(M) if want_moments else None
         lp, am, mx, fused = C.c_double(0.0), C.c_long(-1), C.c_double(0.0), C.c_int(0)
         _check(load_library().boss_gp_update_acq(self._h, _dp(lam), float(amplitude), float(noise_std), _dp(m), cand._h, _dp(ms),
-                                                 float(fit_coef), float(y_max), 0 if best is None else 1,
+                                                 float(fit_coef), float("nan") if y_max is None else float(y_max), 0 if best is None else 1,
                                                  0.0 if best is None else float(best), _ucp(mask), C.byref(lp), _dp(mu), _dp(var),
                                                  _dp(acq), C.byref(am), C.byref(mx), C.byref(fused)))
         self.logpdf = lp.value

@@ -59,6 +59,11 @@ __device__ __forceinline__ double ei_value(const double* __restrict__ mu, const 
     return poison ? -INFINITY : acq;
 }
 
+// the same for ONE output whose moments are in registers (rider_final_kernel)
+__device__ __forceinline__ double ei_value_one(double m, double v, const EiPar& par) {
+    return ei_value(&m, &v, 1, 0, par, nullptr, nullptr);
+}
+
 // BI: acq_sum[j] += acq_s(x_j) for every hyper-parameter sample but the last (the last one is folded
 // into acq_epilogue_kernel).
 __global__ void ei_accumulate_kernel(const double* __restrict__ mu, const double* __restrict__ var, int ldm, int M,

@@ -25,6 +25,7 @@
 // fixed order: repeated calls are bit-identical.
 #pragma once
 #include "chain.hpp"
+#include "acq_kernels.hpp"
 
 namespace boss {
 
@@ -136,7 +137,10 @@ struct RiderStep {
     const unsigned long long* sig;                           // the context's signal block
     int* info;
     unsigned long long want;                                 // value the watched words must reach before block k is solved
-    int ld, Np, N, Mp, d, kern, k, nblk, nstrips, nslots, cb, nchunks;
+    int ld, Np, N, Mp, d, kern, k, nblk, nstrips, nslots, cb, nchunks, xcd_map;
+#ifdef BOSS_EXPERIMENTS
+    int exp;                                                 // timing experiments: bit 0 skips the E products, bit 1 the fold products, bit 2 sleeps between E products
+#endif
     unsigned budget;
     double amp2;
 };
@@ -169,8 +173,19 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
         // ---------------- E_k: block row k+1, one (strip, chunk) item per workgroup; chunk ch takes the blocks
         // [ch·cb, min((ch+1)·cb, k-1)), its first half on waves 0..3, the second on waves 4..7 (summed through LDS in that order) —
         // strips fastest: the workgroups of a chunk share their slice of L
+        // Workgroup b runs on XCD b mod 8 (workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own): where the
+        // chunk count divides eight, every XCD serves ONE chunk — its slice of L[k+1, ·] comes over the fabric once instead of eight times
+        // (at k = 30, 1024 candidates: 4 instead of 31 MB per step, beside the 31 MB of V) — the fabric the chain's hand-offs travel on.
         const int item = (int)blockIdx.x - nstrips;
-        const int strip = item % nstrips, ch = item / nstrips;
+        int strip, ch;
+        if (p.xcd_map && (8 % p.nchunks) == 0 && ((nstrips * p.nchunks) & 7) == 0) {
+            const int x = (int)blockIdx.x & 7, t = item >> 3, per = 8 / p.nchunks;
+            ch = x % p.nchunks;
+            strip = t * per + x / p.nchunks;
+        } else {
+            strip = item % nstrips;
+            ch = item / nstrips;
+        }
         const int krow = k + 1, j0 = ch * p.cb, j1 = min(j0 + p.cb, k - 1);
         const int jm = j1 - j0 >= 2 ? j0 + (j1 - j0 + 1) / 2 : j1;   // group 0: [j0, jm), group 1: [jm, j1)
         const int ja = grp == 0 ? j0 : jm, jz = grp == 0 ? jm : j1;
@@ -181,6 +196,9 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
         }
+#ifdef BOSS_EXPERIMENTS
+        if (!(p.exp & 1))
+#endif
         if (jz > ja)
             rider_gemm(p.V + (size_t)strip * Np * 32 + (size_t)ja * BLK * 32, p.A + (size_t)krow * BLK + (size_t)ja * BLK * ld, ld, (jz - ja) * BLK, acc, grp);
         if (j1 > jm) {                                       // (uniform over the workgroup)
@@ -257,6 +275,9 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
             }
         }
         const int jb = k >= 2 ? k - 2 + grp : (grp == 0 ? 0 : -1);   // the block of V this group multiplies
+#ifdef BOSS_EXPERIMENTS
+        if (!(p.exp & 2))
+#endif
         if (jb >= 0)
             rider_gemm(p.V + (size_t)strip * Np * 32 + (size_t)jb * BLK * 32, p.A + (size_t)k * BLK + (size_t)jb * BLK * ld, ld, BLK, acc, grp);
     }
@@ -433,52 +454,150 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
     RTRACE_MAX(k, 2);
 }
 
-// μ, σ² (unclipped, as the prediction kernels leave them): one workgroup per 32 candidates, eight threads per candidate — thread
-// (candidate c, g) takes the g-th group of sixteen rows of the last two blocks' v·z and every eighth block of the per-block partial sums.
-__global__ __launch_bounds__(256) void rider_final_kernel(const double* __restrict__ A, int ld, int Np, int nblk,
-                                                          const double* __restrict__ V, const double* __restrict__ part_ss,
-                                                          const double* __restrict__ part_z, const double* __restrict__ mean_s,
-                                                          int M, int Mp, double amp2, double* __restrict__ mu_out,
-                                                          double* __restrict__ var_out, const int* __restrict__ info,
-                                                          double* __restrict__ host_res) {
-    // the factorisation's flag as it stands behind the rider's last gate, for the host (mapped memory, read when the epilogue's
-    // sequence word arrives): a wait of the rider that gave up after the update's own kernels had passed leaves INT_MIN here
-    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(host_res + 3)[0] = ld_info_fresh(info);
+// The rider's tail in ONE launch behind the last step: μ, σ² (unclipped, as the prediction kernels leave them), the EI × feasibility
+// epilogue of acq_epilogue_kernel (expected_improvement.jl:68-101) and the first-index arg-max.  One workgroup per 32 candidates,
+// eight threads per candidate — thread (candidate c, g) takes every eighth block of the per-block partial sums BEFORE the
+// workgroup waits for the update's last kernel (the z entries of the last two blocks are final then), afterwards the g-th sixteen
+// rows of those blocks' v·z.  Each workgroup leaves its (max, index) pair write-through; the one that counts itself in last reduces
+// the pairs and answers the host through mapped memory (value, index, the factorisation's flag, then the sequence word it polls).
+struct RiderFinal {
+    const double *A, *V, *part_ss, *part_z, *mean_s;
+    double *mu, *var, *acq;                                  // device arrays (M)
+    const unsigned char* mask;
+    const int* info;
+    double* host_res;                                        // mapped: {max, arg-max, sequence word, flag}
+    const unsigned long long* gate;                          // sig[SIGW_GATE] >= want: the update's last kernel has started
+    unsigned long long want, done_after, res_seq;
+    unsigned long long* done;                                // device counter of finished workgroups (grows by the grid size per call)
+    double* pairs;                                           // [workgroup][2]
+    int ld, Np, nblk, M, Mp;
+    unsigned budget;
+    double amp2;
+    EiPar par;
+};
+__global__ __launch_bounds__(256) void rider_final_kernel(RiderFinal p) {
     RTRACE_MIN(63, 0);
-    __shared__ double sz[2][8][32], sp[2][8][32];
+    __shared__ double sz[2][8][32], sp[2][8][32], bvs[32];
+    __shared__ long bis[32];
+    __shared__ int lastflag;
+    constexpr long NONE = 0x7fffffffffffffffL;
     const int tid = threadIdx.x, cl = tid & 31, g = tid >> 5, c = blockIdx.x * 32 + cl;
-    const double* vp = V + (size_t)blockIdx.x * Np * 32 + cl;
+    const int nblk = p.nblk, Mp = p.Mp, ld = p.ld;
+    double ss = 0.0, zz = 0.0;
+    for (int k = g; k < nblk; k += 8) ss += p.part_ss[(size_t)k * Mp + c];
+    for (int k = g; k < nblk - 2; k += 8) zz += p.part_z[(size_t)k * Mp + c];
+    sp[0][g][cl] = ss;
+    sp[1][g][cl] = zz;
+    if (tid < 64) {                                          // (one wave)
+        const PollTimer tm(p.budget);
+        bool ok = false;
+        for (int it = 0; it < POLL_CAP; ++it) {
+            if (ld_word(p.gate) >= p.want) {
+                ok = true;
+                break;
+            }
+            const int st = tm.check(it, p.info);
+            if (st == 2) {
+                ok = true;                                   // (given up elsewhere: the host discards what follows)
+                break;
+            }
+            if (st == 1) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && tid == 0) {
+            st_info(const_cast<int*>(p.info), INT_MIN);
+            note_giveup(11, 0);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the z entries were written while this kernel was already running
+    const double* vp = p.V + (size_t)blockIdx.x * p.Np * 32 + cl;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {                             // blocks nblk-2, nblk-1 (the steps behind them never ran)
         const int kb = nblk - 2 + b;
+        const double* vq = vp + (size_t)(kb * BLK + g * 16) * 32;
+        const double* zq = p.A + (size_t)(kb * BLK + g * 16) * ld + p.Np;
         double s = 0.0;
-        if (kb >= 0) {
-            const double* vq = vp + (size_t)(kb * BLK + g * 16) * 32;
-            const double* zq = A + (size_t)(kb * BLK + g * 16) * ld + Np;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) s = __builtin_fma(vq[(size_t)j * 32], zq[(size_t)j * ld], s);
-        }
+        for (int j = 0; j < 16; ++j) s = __builtin_fma(vq[(size_t)j * 32], ld_sc1(zq + (size_t)j * ld), s);
         sz[b][g][cl] = s;
     }
-    double ss = 0.0, zz = 0.0;
-    for (int k = g; k < nblk; k += 8) ss += part_ss[(size_t)k * Mp + c];
-    for (int k = g; k < nblk - 2; k += 8) zz += part_z[(size_t)k * Mp + c];
-    sp[0][g][cl] = ss;
-    sp[1][g][cl] = zz;
     __syncthreads();
-    if (g != 0 || c >= M) return;
-    double s = sp[0][0][cl], z = sp[1][0][cl], z0 = sz[0][0][cl], z1 = sz[1][0][cl];
+    if (g == 0) {
+        double bv = -INFINITY;
+        long bi = NONE;
+        if (c < p.M) {
+            double s = sp[0][0][cl], z = sp[1][0][cl], z0 = sz[0][0][cl], z1 = sz[1][0][cl];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) {
-        s += sp[0][q][cl];
-        z += sp[1][q][cl];
-        z0 += sz[0][q][cl];
-        z1 += sz[1][q][cl];
+            for (int q = 1; q < 8; ++q) {
+                s += sp[0][q][cl];
+                z += sp[1][q][cl];
+                z0 += sz[0][q][cl];
+                z1 += sz[1][q][cl];
+            }
+            z = (z + z0) + z1;
+            const double mu_c = (p.mean_s ? p.mean_s[c] : 0.0) + z, var_c = p.amp2 - s + PREDICT_JITTER;
+            p.mu[c] = mu_c;
+            p.var[c] = var_c;
+            double a = ei_value_one(mu_c, var_c, p.par);
+            if (p.mask && !p.mask[c]) a = 0.0;
+            p.acq[c] = a;
+            bv = a;
+            bi = c;
+        }
+        bvs[cl] = bv;
+        bis[cl] = bi;
     }
-    z = (z + z0) + z1;
-    mu_out[c] = (mean_s ? mean_s[c] : 0.0) + z;
-    var_out[c] = amp2 - s + PREDICT_JITTER;
+    __syncthreads();
+    if (tid == 0) {
+        double bv = bvs[0];
+        long bi = bis[0];
+        for (int q = 1; q < 32; ++q)
+            if (bis[q] != NONE && (bi == NONE || better(bvs[q], bis[q], bv, bi))) {
+                bv = bvs[q];
+                bi = bis[q];
+            }
+        st_sc1(p.pairs + 2 * (size_t)blockIdx.x, bv);
+        st_sc1(p.pairs + 2 * (size_t)blockIdx.x + 1, __longlong_as_double((long long)bi));
+        drain_stores();
+        const unsigned long long before = __hip_atomic_fetch_add(as_global(p.done), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *(volatile lds_int_t*)&lastflag = (before + 1 == p.done_after) ? 1 : 0;
+    }
+    __syncthreads();
     RTRACE_MAX(63, 2);
+    if (*(volatile lds_int_t*)&lastflag == 0 || tid >= 64) return;
+    // ---- the last workgroup: first-index arg-max over the workgroups' pairs (one wave; at most 256 pairs)
+    // the factorisation's flag as it stands behind the rider's last wait (a wait of the rider that gave up after the update's own
+    // kernels had passed leaves INT_MIN there, and the host discards the rider's numbers): fetched beside the pairs
+    const int info_now = tid == 63 ? ld_info_fresh(p.info) : 0;
+    double bv = -INFINITY;
+    long bi = NONE;
+    for (int w = tid; w < (int)gridDim.x; w += 64) {
+        const double v = ld_sc1(p.pairs + 2 * (size_t)w);
+        const long i = (long)__double_as_longlong(ld_sc1(p.pairs + 2 * (size_t)w + 1));
+        if (i != NONE && (bi == NONE || better(v, i, bv, bi))) {
+            bv = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const long oi = ((long)__shfl_xor((int)(bi >> 32), off) << 32) | (unsigned)__shfl_xor((int)(bi & 0xffffffffL), off);
+        if (oi != NONE && (bi == NONE || better(ov, oi, bv, bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    const int info63 = __shfl(info_now, 63);
+    if (tid == 0) {
+        p.host_res[0] = bv;
+        reinterpret_cast<long*>(p.host_res)[1] = bi;
+        reinterpret_cast<int*>(p.host_res + 3)[0] = info63;
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.host_res) + 2, p.res_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    RTRACE_MAX(63, 3);
 }
 
 }  // namespace boss

@@ -313,6 +313,7 @@ Base.@kwdef struct HipBatchAM <: BOSS.AcquisitionMaximizer
     max_attempts::Int = 200
     devices::Int = 1              # > 1: sharded over that many GPUs inside the library (RCCL), along `shard`
     shard::Symbol = :candidates   # :candidates (BASELINE config 3) | :outputs (config 4) | :samples (config 5)
+    fused::Bool = true            # one output, one parameter sample: posterior update + acquisition as ONE call (boss_gp_update_acq)
 end
 "The candidate columns of one acquisition call (sampling.jl:43-46: draws from `x_prior` inside the domain; or the fixed grid)."
 function candidates(am::HipBatchAM, problem::BOSS.BossProblem)
@@ -339,9 +340,37 @@ function ei_arguments(problem::BOSS.BossProblem, xs::AbstractMatrix{Float64})
     ymax = Float64[c for c in problem.y_max]                               # BOSS.Infinity converts to Inf (src/utils/inf.jl)
     return Float64.(ei.fitness.coefs), ymax, isnothing(b) ? Cint(0) : Cint(1), Float64(something(b, 0.0)), ei.cons_safe ? mask : C_NULL
 end
+"One output, one parameter sample of the plain GP: `model_posterior(problem)` is ONE factorisation, and with candidates that do not
+depend on it (sampling.jl:43-57, grid.jl:52-65) the acquisition can ride along: boss_gp_update_acq (bo.jl:30-48 in one device call)."
+fusable(am::HipBatchAM, problem::BOSS.BossProblem) = am.fused && am.devices == 1 && problem.model isa HipGaussianProcess &&
+    BOSS.y_dim(problem) == 1 && BOSS.get_params(problem) isa HipGPParams
+function update_and_acquire(am::HipBatchAM, problem::BOSS.BossProblem, xs::Matrix{Float64}, return_all::Bool)
+    m = problem.model::HipGaussianProcess; p = BOSS.get_params(problem)::HipGPParams; data = problem.data
+    X = Matrix{Float64}(data.X); y = Vector{Float64}(data.Y[1, :]); M = size(xs, 2); k = m.gp.kernel
+    mu = BOSS.mean_getindex(m.gp.mean, 1)
+    coefs, ymax, hb, b, mask = ei_arguments(problem, xs)
+    h = Ref{Ptr{Cvoid}}(); cand = Ref{Ptr{Cvoid}}()
+    check(ccall((:boss_gp_create, lib), Cint, (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+          m.device, kernel_id(base_kernel(k)), size(X, 1), size(X, 2), X, y, discrete_flags(k), h))
+    gp = Handle(h[])
+    check(ccall((:boss_cand_create, lib), Cint, (Cint, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}), m.device, size(xs, 1), M, xs, cand))
+    acq = return_all ? Vector{Float64}(undef, M) : C_NULL
+    lp = Ref{Cdouble}(); am_idx = Ref{Clong}(); mx = Ref{Cdouble}(); fused = Ref{Cint}()
+    rc = GC.@preserve gp ccall((:boss_gp_update_acq, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cvoid}, Ptr{Cdouble}, Cdouble, Cdouble, Cint, Cdouble, Ptr{UInt8},
+         Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}, Ref{Cdouble}, Ref{Cint}),
+        gp.h, Vector{Float64}(p.λ[:, 1]), p.α[1], p.σ[1], mean_vals(mu, X), cand[], mean_vals(mu, xs), coefs[1], ymax[1], hb, b, mask,
+        lp, C_NULL, C_NULL, acq, am_idx, mx, fused)
+    ccall((:boss_cand_free, lib), Cvoid, (Ptr{Cvoid},), cand[])
+    check(rc)
+    return_all && return xs, acq
+    return xs[:, am_idx[] + 1], mx[]
+end
 function maximize_acquisition(am::HipBatchAM, problem::BOSS.BossProblem, options::BOSS.BossOptions;
-                              posts = BOSS.model_posterior(problem), return_all::Bool = false)
+                              posts = nothing, return_all::Bool = false)
     xs = candidates(am, problem)
+    isnothing(posts) && fusable(am, problem) && return update_and_acquire(am, problem, xs, return_all)
+    isnothing(posts) && (posts = BOSS.model_posterior(problem))
     posts isa AbstractVector || (posts = [posts])                          # BI: a vector of posteriors (src/posterior.jl:15-19)
     P = BOSS.y_dim(problem); S = length(posts); M = size(xs, 2)
     hs = Ptr{Cvoid}[posts[s].slices[p].h.h for p in 1:P, s in 1:S]         # P×S, column-major = gps[p + P*s]

@@ -126,6 +126,8 @@ class HipBatchAM:
     seed: Optional[int] = None
     group: object = None
     shard: str = "candidates"           # "candidates" | "outputs" | "samples"
+    fused: bool = True                  # one output, one parameter sample, LinFitness: the posterior update and the acquisition in ONE device
+    #                                     call (boss_gp_update_acq: the candidates' substitution rides along the factorisation)
     devices: Optional[Sequence[int]] = None   # ONE process driving GPUs 0..G-1: the shard modes run inside the library
     #                                           (boss_multi_*: one host thread per device, exchanges over RCCL) — what a Julia
     #                                           caller uses; None = one process per GPU over torch.distributed (or a single GPU)
@@ -157,6 +159,13 @@ class HipBatchAM:
             return self._maximize_by_samples(problem, Xs, rank, world, return_all)
         assert self.shard == "candidates", self.shard
         lo, hi = dist_util.shard_range(M, rank, world)
+        if posts is None and self.fused and hi > lo and self._fusable(problem):
+            acq, am, mx = self._update_and_acquire(problem, Xs[:, lo:hi], return_all)
+            am += lo
+            if return_all:
+                return Xs, (dist_util.allgather_concat(acq, self.group) if world > 1 else acq)
+            mx, am = dist_util.argmax_exchange(mx, am, self.group)
+            return Xs[:, am].copy(), mx
         if posts is None:
             posts = posteriors_of(problem)
         if hi > lo:
@@ -168,6 +177,32 @@ class HipBatchAM:
             return Xs, (dist_util.allgather_concat(acq, self.group) if world > 1 else acq)
         mx, am = dist_util.argmax_exchange(mx, am, self.group)
         return Xs[:, am].copy(), mx
+
+    @staticmethod
+    def _fusable(problem: BossProblem) -> bool:
+        """`model_posterior(problem)` is ONE factorisation (one output, one parameter sample) of the plain GP / semiparametric
+        model and the acquisition is the analytic EI: the two halves of the BO iteration (src/bo.jl:30-48) fit one device call."""
+        from .model import HipGaussianProcess
+        return (problem is not None and type(problem.model) is HipGaussianProcess and problem.data.Y.shape[0] == 1 and
+                not isinstance(problem.params, (list, tuple)) and not isinstance(problem.acquisition.fitness, NonlinFitness))
+
+    def _update_and_acquire(self, problem: BossProblem, Xs, want_acq: bool):
+        """model_posterior(problem) + acq.(eachcol(xs)) + argmax as boss_gp_update_acq: the posterior of the single output is
+        built under problem.params while the candidates' forward substitution rides along its factorisation."""
+        model, prm, data, ei = problem.model, problem.params, problem.data, problem.acquisition
+        Xs = np.asfortranarray(Xs, dtype=np.float64)
+        mask = (in_bounds(Xs, problem.domain.bounds) & in_cons(Xs, problem.domain.cons)) if ei.cons_safe else None
+        b = best_so_far(ei.fitness, data.Y, problem.y_max)
+        g = api.GP(data.X, data.Y[0], model.kernel, model.discrete, model.device)
+        cand = api.Candidates(Xs, model.device)
+        try:
+            r = g.update_acq(prm.lengthscales[:, 0], prm.amplitudes[0], prm.noise_std[0], cand, fit_coef=float(np.asarray(ei.fitness.coefs)[0]),
+                             y_max=float(np.asarray(problem.y_max, float)[0]), best=b, mean_X=model.mean_values(data.X, prm, 0),
+                             mean_Xs=model.mean_values(Xs, prm, 0), valid_mask=mask, want_acq=want_acq)
+        finally:
+            cand.close()
+            g.close()
+        return r["acq"], r["argmax"], r["max"]
 
     def _maximize_in_library(self, problem: BossProblem, Xs, return_all):
         """The three shard modes with ONE process driving the devices: posteriors are created on the devices the mode

@@ -274,7 +274,8 @@ int boss_acq_ei(int P, int S, boss_gp_t* const* gps, const boss_cand_t* cand,
  * mean_and_var :174-178 + construct_ei, src/acquisitions/expected_improvement.jl:68-101) on the SAME handle.
  *   gp, lengthscale, amplitude, noise_std, mean_X: as boss_gp_update;   cand: resident candidates on gp's device;
  *   mean_Xs  NULL or M prior means at the candidates;   fit_coef: the LinFitness coefficient of this output;
- *   y_max    the output's upper constraint, +Inf = unconstrained;   has_best / best, valid_mask: as boss_acq_ei;
+ *   y_max    the output's upper constraint (+Inf allowed: factor 1, src/utils/inf.jl); NaN = `constraints === nothing`
+ *            (boss_acq_ei's y_max == NULL);   has_best / best, valid_mask: as boss_acq_ei;
  *   logpdf_out  the update's log marginal likelihood;   mu_out / var_out  M posterior moments (unclipped: what
  *       mean_and_var returns before _clip_var; the EI epilogue clips) or NULL;   acq_out  M values or NULL;
  *   argmax_out / max_out as boss_acq_ei;   fused_out (or NULL): 1 = the substitution rode along, 0 = the call ran the two

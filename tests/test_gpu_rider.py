@@ -204,3 +204,26 @@ for i in range(3):
         assert r.returncode == 0 and len(lines) == 3, r.stdout + r.stderr
         for fused, e_lp, e_acq, same in lines:
             assert fused == "0" and float(e_lp) <= 1e-9 and float(e_acq) <= 1e-9 and same == "True", (env, lines)
+
+
+def test_batch_maximizer_takes_the_fused_call(api, O):
+    """HipBatchAM on a one-output problem: model_posterior(problem) + acq.(eachcol(xs)) + argmax as ONE device call
+    (maximize_acquisition, src/acquisition_maximizers/sampling.jl:20-57) — same point and value as the two-phase path, semiparametric
+    mean, constraint function and an upper constraint included."""
+    import boss_jl_amd as B
+    from boss_jl_amd.model import HipGPParams
+    d, N, M = 3, 700, 400
+    X, y, Xs = make(d, N, M, seed=11)
+    model = B.HipGaussianProcess(lengthscale_priors=[B.MvLogNormal([0.] * d, [1.] * d)], amplitude_priors=[B.LogNormal()],
+                                 noise_std_priors=[B.LogNormal()], kernel="matern32", mean=lambda x: [0.1 + 0.2 * x[0]])
+    for y_max, cons in ((None, None), ([0.9], lambda x: [x[1] - 0.2])):
+        problem = B.BossProblem(f=None, domain=B.Domain(bounds=([0.1] * d, [0.9] * d), cons=cons), y_max=y_max,
+                                acquisition=B.ExpectedImprovement(B.LinFitness([1.5])), model=model, data=B.ExperimentData(X, y[None, :]))
+        problem.params = HipGPParams(np.full((d, 1), 0.4), [1.1], [0.05])
+        problem.consistent = True
+        x1, v1 = B.HipBatchAM(points=Xs, fused=True).maximize_acquisition(problem)
+        x0, v0 = B.HipBatchAM(points=Xs, fused=False).maximize_acquisition(problem)
+        assert np.array_equal(x1, x0) and abs(v1 - v0) <= 1e-9
+        _, a1 = B.HipBatchAM(points=Xs, fused=True).maximize_acquisition(problem, return_all=True)
+        _, a0 = B.HipBatchAM(points=Xs, fused=False).maximize_acquisition(problem, return_all=True)
+        assert np.all(np.abs(a1 - a0) <= 1e-9) and a1.max() == v1

@@ -4,7 +4,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 entry.build()
+import os as _os
 from boss_jl_amd import api
+if os.environ.get('BOSS_LIB_PATH'): api.load_library(os.environ['BOSS_LIB_PATH'])
 N, D = int(os.environ.get("N", 4096)), 8
 rng = np.random.default_rng(1)
 X = rng.uniform(0, 1, (D, N)); y = np.sin(2 * np.pi * X).sum(0) / np.sqrt(D) + 0.05 * rng.standard_normal(N)
