@@ -502,19 +502,33 @@ def main():
                       "serialised_ms_diag": ms_diag / reps, "serialised_ms_trsm": ms_trsm / reps,
                       "serialised_ms_syrk": ms_syrk / reps}
 
-    # ---- latency distribution of the posterior update (the resident chain's tail latency): 240 back-to-back updates
+    # ---- latency distribution of the posterior update (the resident chain's tail latency): 2000 back-to-back updates, every launch
+    # of each stamped on the host (csrc/host_factor.inc, LaunchStamps): an update beyond 2 ms reports where its submission stood still
     upd_dist = None
     note("update latency distribution")
     if rank == 0:
-        ts = []
-        for i in range(240):
+        import ctypes as C
+        lib = api.load_library()
+        lib.boss_debug_launch_stamps.argtypes = [C.c_int, C.c_double]
+        lib.boss_debug_stall_report.argtypes = [C.c_char_p, C.c_int]
+        lib.boss_debug_launch_stamps(1, 2.0)
+        rep = C.create_string_buffer(8192)
+        lib.boss_debug_stall_report(rep, 8192)                      # (clears what the serialised profiling pass above left)
+        nlat = 2000
+        ts = np.empty(nlat)
+        for i in range(nlat):
             t0 = time.perf_counter()
             gp.update(lam, 1.0, 0.05 + 1e-4 * (i % 7))
-            ts.append(time.perf_counter() - t0)
-        ts = np.sort(np.array(ts)) * 1e3
+            ts[i] = time.perf_counter() - t0
+        lib.boss_debug_stall_report(rep, 8192)
+        lib.boss_debug_launch_stamps(0, 0.0)
+        ts = np.sort(ts) * 1e3
         upd_dist = {"n": int(ts.size), "update_ms_p50": float(np.percentile(ts, 50)), "update_ms_p90": float(np.percentile(ts, 90)),
-                    "update_ms_p99": float(np.percentile(ts, 99)), "update_ms_max": float(ts[-1]), "update_ms_min": float(ts[0]),
-                    "update_ms_mean": float(ts.mean())}
+                    "update_ms_p99": float(np.percentile(ts, 99)), "update_ms_p999": float(np.percentile(ts, 99.9)),
+                    "update_ms_max": float(ts[-1]), "update_ms_min": float(ts[0]), "update_ms_mean": float(ts.mean()),
+                    "max_over_p50": float(ts[-1] / np.percentile(ts, 50)),
+                    "updates_beyond_2ms": int((ts > 2.0).sum()),
+                    "stall_reports": [ln for ln in rep.value.decode(errors="replace").splitlines() if ln][:8]}
 
     # ---- SURVEY §8f rows built beyond the headline path (rank 0, N=1 only; a fraction of a second)
     extras = None

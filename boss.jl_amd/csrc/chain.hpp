@@ -35,7 +35,7 @@ __device__ unsigned long long g_ctrace[64 * 16];
 // (follower rounds waiting on scratch loads: 10 µs each); as separate non-inlined functions each call saves and restores
 // 40-48 callee-saved registers through scratch on the step's critical path.  Cutting every live range at the phase boundary
 // costs one reload of the thread index per phase.
-#define CHAIN_CUT_VGPRS() asm volatile("" ::: "memory", "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119")   // (v120-v127 stay: SGPR spill lanes, the thread index)
+#define CHAIN_CUT_VGPRS() asm volatile("" ::: "memory", "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111")   // (v112-v127 stay: a zero accumulator the compiler keeps for every MFMA chain — cut too, it went through scratch at every cut —, SGPR spill lanes, the thread index)
 constexpr int STRIPS_LDS_BYTES = 90 * 1024;                  // occupancy limiter of potrf_strips_kernel (see chain_begin)
 constexpr int CHAIN_CTRL = DIAG_TILES * 256 + DIAG_STAGE;   // doubles: one control word behind the diagonal-block kernel's LDS
 constexpr int CHAIN_LDS_BYTES = (CHAIN_CTRL + 2) * 8;       // two control words (ints): go-ahead of the block, posted panel count
@@ -198,25 +198,35 @@ __device__ __forceinline__ void chain_factor_phase(double* __restrict__ Ab, int 
     diag_block_factor<false, false, true>(smem, Ab, ld, inv16b, col0, 8, fail, nullptr, pubword, seq0, info, tid + 0x10000);
 }
 
+// this lane's index, rebuilt from the lane count behind an optimisation barrier: whatever is derived from it is computed where it is
+// used instead of being hoisted out of the block loop and kept alive (= spilled to scratch) across the phase cuts
+__device__ __forceinline__ int chain_lane_opaque() {
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __restrict__ A, int ld, int nblk,
                                                                    double* __restrict__ inv16, int* __restrict__ info,
                                                                    unsigned long long* __restrict__ sig, unsigned long long base,
                                                                    unsigned long long cbase, unsigned budget) {
     extern __shared__ double smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     volatile lds_int_t* ctrl = (volatile lds_int_t*)(unsigned)(unsigned long long)(smem + CHAIN_CTRL);
     // The workgroup keeps its CU to itself: 16 waves × 128 registers fill every SIMD's register file, so no follower or bulk wave
     // can settle beside the pivot-chain wave (a co-resident wave on that SIMD stretches the chain 3980 -> 5450 cycles per panel).
     asm volatile("" ::: "v127");
-    if (tid == 0) __hip_atomic_fetch_add(as_global(sig + SIGW_UP), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (chain_ready_kernel)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(as_global(sig + SIGW_UP), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // resident (chain_ready_kernel)
+    // No per-lane value lives across an iteration of this loop or across the phase cuts inside it (the kernel ran with 21 spilled
+    // registers and 16 scratch accesses per block before: the thread index and the hoisted addresses of the b = 0 copy): every use
+    // of the lane index below rebuilds it (chain_lane_opaque).
     for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
         double* Ab = A + (size_t)b * BLK * ((size_t)ld + 1);
         // ---- block b with every panel < b-1 applied: the Gram matrix itself (b = 0, 1: the first follow kernel has started) or
         // tile (b, b) as the critical strips of step b-2's column update stored it (sig[SIGW_CRIT] >= cbase + 8 (b-1))
         if (wave == 0) {
             const bool ok = b < 2 ? poll_ge(sig + SIGW_WDONE, base + 1, info, budget) : poll_ge(sig + SIGW_CRIT, cbase + 8ull * (b - 1), info, budget);
-            if (lane == 0) {
+            if (chain_lane_opaque() == 0) {
                 *ctrl = ok ? 1 : -1;
                 ctrl[1] = 0;                                  // (the follower phase's posted panel count)
             }
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_chain_kernel(double* __res
         if (wave == 0) CTRACE(b, 0);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // written by kernels that ran while this one was resident
         if (b == 0) {
+            const int lane = chain_lane_opaque();
             for (int tl = wave; tl < DIAG_TILES; tl += DIAG_THREADS / 64) {
                 int ti = 0;
                 while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
