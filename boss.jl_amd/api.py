@@ -535,15 +535,23 @@ def fit_batch(X, y, kernel, lengthscales, amplitudes, noise_stds, mean_X=None, d
     sig = _f64(np.asarray(noise_stds).reshape(-1), 1)
     if amp.shape[0] != S or sig.shape[0] != S:
         raise BossError(BOSS_E_INVALID, "amplitudes and noise_stds must have one entry per set")
+    if y.shape[0] != N:
+        raise ValueError("y must have one entry per column of X")           # (as GP.__init__: the library copies N entries)
+    if not (np.isfinite(amp).all() and np.isfinite(sig).all() and np.isfinite(lam).all()):
+        raise BossError(BOSS_E_INVALID, "hyper-parameters must be finite")
     stride = 0
     m = None
     if mean_X is not None:
         m = np.asarray(mean_X, dtype=np.float64)
         if m.ndim == 2:
+            if m.shape != (S, N):
+                raise ValueError("mean_X must be S×N (one prior-mean row per set) or a vector of N entries")
             m = np.ascontiguousarray(m)
             stride = N
         else:
             m = np.ascontiguousarray(m.reshape(-1))
+            if m.shape[0] != N:
+                raise ValueError("mean_X must be S×N (one prior-mean row per set) or a vector of N entries")
     disc = None if discrete is None else np.ascontiguousarray(np.asarray(discrete, dtype=bool).astype(np.uint8))
     hs = (C.c_void_p * S)()
     ll = np.zeros(S)

@@ -59,10 +59,18 @@ constexpr size_t PINNED_UP_OFF = 4096, PINNED_UP_BYTES = 1024 * 1024, PINNED_DOW
 
 // every device allocation goes through here; BOSS_POISON_ALLOC=1 (tests) fills new memory with NaN bit patterns so that
 // reads of never-written memory show up instead of passing on the zeros a fresh process happens to get
+static bool release_cached_slabs();                        // (defined with the contexts below)
+static std::atomic<int> g_fail_allocs{0};                  // tests (boss_debug_fail_next_alloc): that many first attempts report "out of memory"
 static hipError_t dev_malloc(void** p, size_t bytes) {
     static const bool poison = getenv("BOSS_POISON_ALLOC") && atoi(getenv("BOSS_POISON_ALLOC"));
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = hipErrorOutOfMemory;
+    if (g_fail_allocs.load(std::memory_order_relaxed) > 0 && g_fail_allocs.fetch_sub(1) > 0) *p = nullptr;
+    else e = hipMalloc(p, bytes);
     if (e != hipSuccess) (void)hipGetLastError();            // a failed allocation must not surface later as a stale launch error
+    if (e != hipSuccess && release_cached_slabs()) {         // the parked storage of a released set (up to 4.5 GB at BASELINE config 5) may be what stands in the way
+        e = hipMalloc(p, bytes);
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
     if (e == hipSuccess && poison) {
         (void)hipMemset(*p, 0xff, bytes);                    // null stream: the library's streams do not wait for it ...
         (void)hipDeviceSynchronize();                        // ... so finish it before anything else touches the block
@@ -93,6 +101,7 @@ struct Ctx {
     // hipStreamWaitValue64 is fast (2.6 µs) but its polling wave slows whatever shares its SIMD by 2x
     // (tools/streamwait_probe.hip, profiles/r02_chain_timeline_waitvalue.log).  nullptr (BOSS_NO_GATE=1): events.
     unsigned long long* sig_panel = nullptr;
+    unsigned long long* sig_panel_host = nullptr;   // BOSS_DEBUG_WATCH: the signal words live in mapped host memory (sig_panel is its device alias; a watcher thread reads it)
     unsigned long long sig_seq = 0;
     // the resident panel chain (chain.hpp): its own stream, the base of its sequence numbers, and whether it may be used at all
     // (it needs kernels of different streams to run at the same time: off wherever launches are known to be serialised)
@@ -138,6 +147,41 @@ static void chain_quiesce(Ctx* c) {
 static std::mutex g_ctx_mtx;
 static std::map<int, Ctx*> g_ctx;
 
+// Every context's parked set storage on the CURRENT device goes back to the runtime (dev_malloc: an allocation failed).  True when
+// something was freed.  Never called with g_ctx_mtx or a slab_mtx held.
+static bool release_cached_slabs() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mtx);
+        for (auto& kv : g_ctx) {
+            Ctx* c = kv.second;
+            if (c->device != dev) continue;
+            std::lock_guard<std::mutex> sl(c->slab_mtx);
+            if (c->slab_cache) blocks.push_back(c->slab_cache);
+            c->slab_cache = nullptr;
+            c->slab_cache_bytes = 0;
+        }
+    }
+    for (void* b : blocks) (void)hipFree(b);
+    return !blocks.empty();
+}
+extern "C" int boss_debug_fail_next_alloc(int n) {         // (tests: the next n device allocations fail their first attempt)
+    g_fail_allocs.store(n > 0 ? n : 0);
+    return BOSS_OK;
+}
+extern "C" int boss_debug_slab_cache_bytes(int device, size_t* bytes_out) {   // (tests: how much released set storage the context keeps)
+    std::lock_guard<std::mutex> lk(g_ctx_mtx);
+    auto it = g_ctx.find(device);
+    if (bytes_out) *bytes_out = 0;
+    if (it != g_ctx.end() && bytes_out) {
+        std::lock_guard<std::mutex> sl(it->second->slab_mtx);
+        *bytes_out = it->second->slab_cache_bytes;
+    }
+    return BOSS_OK;
+}
+
 static void ctx_destroy(Ctx* c) {
     if (!c) return;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -145,7 +189,7 @@ static void ctx_destroy(Ctx* c) {
     if (c->chain_stream) (void)hipStreamDestroy(c->chain_stream);
     if (c->strip_stream) (void)hipStreamDestroy(c->strip_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->sig_panel) (void)hipFree(c->sig_panel);
+    if (c->sig_panel && !c->sig_panel_host) (void)hipFree(c->sig_panel);   // (watch mode: the detached watcher thread keeps reading the block — it stays)
     if (c->few_done) (void)hipFree(c->few_done);
     if (c->slab_cache) (void)hipFree(c->slab_cache);
     if (c->hostblk_cache) (void)hipHostFree(c->hostblk_cache);
@@ -196,6 +240,7 @@ static int ctx_init(Ctx* c) {
                 HIPCHK(hipHostMalloc((void**)&hp, SIG_WORDS * sizeof(unsigned long long), hipHostMallocMapped));
                 std::memset(hp, 0, SIG_WORDS * sizeof(unsigned long long));
                 HIPCHK(hipHostGetDevicePointer((void**)&c->sig_panel, hp, 0));
+                c->sig_panel_host = hp;
 #ifdef BOSS_DEBUG_WATCH_BUILD
                 HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(boss::g_dbg), &c->sig_panel, sizeof(void*)));
 #endif

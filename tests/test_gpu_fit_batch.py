@@ -257,3 +257,39 @@ def test_released_storage_is_reused_without_leaking_into_the_next_set(api, O):
         for g in gps[1:]:
             g.close()
     keep[0].close()
+
+
+def test_parked_set_storage_is_given_back_when_an_allocation_fails(api):
+    """The storage of a released set stays with its context for the next fit of that size (hipMalloc / hipFree of gigabytes cost up to
+    half a second on some boxes).  It must not stand in the way of anything else: an allocation that fails drops it and tries again
+    (dev_malloc, csrc/bosship.hip) — here with a simulated failure, so that the test does not have to fill 288 GB."""
+    import ctypes as C
+    lib = api.load_library()
+    rng = np.random.default_rng(0)
+    d, N, S = 4, 700, 6
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(2 * np.pi * X).sum(0)
+    gps, ll, st = api.fit_batch(X, y, "matern52", np.full((d, S), 0.4), np.ones(S), np.full(S, 0.1))
+    assert (st == 0).all()
+    for g in gps:
+        g.close()
+    nbytes = C.c_size_t(0)
+    lib.boss_debug_slab_cache_bytes.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
+    lib.boss_debug_slab_cache_bytes(0, C.byref(nbytes))
+    if nbytes.value == 0:
+        pytest.skip("slab cache off (BOSS_SLAB_CACHE=0 / BOSS_POISON_ALLOC=1)")
+    lib.boss_debug_fail_next_alloc(1)
+    g = api.GP(X, y, "matern52")                                  # its first allocation "fails": the parked block goes, the retry succeeds
+    lib.boss_debug_fail_next_alloc(0)
+    lib.boss_debug_slab_cache_bytes(0, C.byref(nbytes))
+    assert nbytes.value == 0
+    lp = g.update(np.full(d, 0.4), 1.0, 0.1)
+    assert abs(lp - ll[0]) <= 1e-9 * (1 + abs(ll[0]))
+    g.close()
+    lib.boss_debug_fail_next_alloc(1)                             # nothing parked any more: the failure surfaces as BOSS_E_ALLOC
+    with pytest.raises(api.BossError) as e:
+        api.GP(X, y, "matern52")
+    lib.boss_debug_fail_next_alloc(0)
+    assert e.value.code == api.BOSS_E_ALLOC
+    g = api.GP(X, y, "matern52")
+    g.close()
