@@ -93,6 +93,32 @@ def pmc_traffic(kernel_substr):
     return None, ("no counter summary for this source tree" + (f" (newest is {stale}, collected on other sources)" if stale else ""))
 
 
+def pmc_mfma(kernel_substr):
+    """Matrix-pipe counters of `kernel_substr` from the third --pmc pass of tools/collect_profiles.sh (same source-hash rule as
+    pmc_traffic): SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES (busy cycles of the MFMA pipes, counted per SIMD, over the busy cycles of
+    the kernel's CUs), MfmaUtil over the whole chip, and the fp64 FLOP the counters saw per launch (SQ_INSTS_VALU_MFMA_MOPS_F64 × 512)."""
+    import glob
+    import re
+    import __graft_entry__ as entry
+    want = entry.source_hash()
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")),
+                   key=lambda q: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(q))])
+    for path in reversed(paths):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("source_hash") != want:
+            continue
+        for k, v in d.items():
+            if isinstance(v, dict) and kernel_substr in k and v.get("mfma_busy_cycles"):
+                return {"kernel": k.split("(")[0][-60:], "mfma_busy_over_busy_cu": v.get("mfma_busy_over_busy_cu"),
+                        "mfma_busy_frac_per_simd": (v.get("mfma_busy_over_busy_cu") or 0.0) / 4.0, "mfma_util_chip": v.get("mfma_util_chip"),
+                        "counted_fp64_flop_per_launch": (v.get("mfma_mops_f64") or 0.0) * 512.0, "launches": v.get("mfma_launches"),
+                        "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def cpu_baseline(X, y, Xs, lam):
     """The CPU oracle on this host's cores: posterior updates the way the reference's stack computes them — pairwise
     distances in the ‖a‖²+‖b‖²−2a·b form with the cross term from one dgemm (Distances.jl; src/models/utils/kernels.jl:35),
@@ -327,6 +353,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the next_rows measurements (counter-collection passes)")
+    ap.add_argument("--with-config5", action="store_true", help="with --no-extras: still run the batched / config-5 block (counter passes of its kernels)")
     ap.add_argument("--inproc-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -490,7 +517,10 @@ def main():
                 # a dependence-free fp64 MFMA stream with ONE wave per SIMD (this kernel's register budget) retires 68.3 TFLOP/s
                 # on 256 CUs (profiles/r03_mfma_rate_probe.log; four waves: 76.6)
                 "one_wave_per_simd_issue_rate_tflops": ONE_WAVE_ISSUE_TFLOPS,
-                "frac_vs_one_wave_issue_rate": ach / ONE_WAVE_ISSUE_TFLOPS}
+                "frac_vs_one_wave_issue_rate": ach / ONE_WAVE_ISSUE_TFLOPS,
+                # matrix-pipe counters of the same command (third --pmc pass; null until collected on these sources)
+                "mfma_counters": pmc_mfma("predict_kernel<"),
+                "mfma_busy_frac": (pmc_mfma("predict_kernel<") or {}).get("mfma_busy_frac_per_simd")}
         # the factorisation: N^3/3 over the whole posterior update (two-stream look-ahead; the
         # per-class event times below come from the serialised profiling pass)
         fl_potrf = N_OBS ** 3 / 3
@@ -500,7 +530,11 @@ def main():
                       "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach2 / FP64_MFMA_PEAK_TFLOPS,
                       "ms_per_update": t_upd_s * 1e3,
                       "serialised_ms_diag": ms_diag / reps, "serialised_ms_trsm": ms_trsm / reps,
-                      "serialised_ms_syrk": ms_syrk / reps}
+                      "serialised_ms_syrk": ms_syrk / reps,
+                      "mfma_counters": {"potrf_colupd_kernel": pmc_mfma("potrf_colupd_kernel"),
+                                        "potrf_syrk_kernel<2,true>": pmc_mfma("potrf_syrk_kernel<2, true>") or pmc_mfma("potrf_syrk_kernel<2"),
+                                        "predict_kernel_set": pmc_mfma("predict_kernel_set")},
+                      "mfma_busy_frac": (pmc_mfma("potrf_colupd_kernel") or {}).get("mfma_busy_frac_per_simd")}
 
     # ---- latency distribution of the posterior update (the resident chain's tail latency): 2000 back-to-back updates, every launch
     # of each stamped on the host (csrc/host_factor.inc, LaunchStamps): an update beyond 2 ms reports where its submission stood still
@@ -621,11 +655,11 @@ def main():
 
     # ---- what DESIGN.md claims beyond the single-matrix chain, in the driver's own record (rank 0; N=1 only for the device work)
     batched = acq_by_m = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and (not args.no_extras or args.with_config5):
         note("batched updates, config 5, acquisition by call size")
         batched = {}
         rs = np.random.default_rng(4)
-        for S in (8, 32):                                              # boss_gp_loglike_batch at N=4096: S hyper-parameter sets per call
+        for S in (2, 4, 8, 32):                                        # boss_gp_loglike_batch at N=4096: S hyper-parameter sets per call
             lamS = np.exp(rs.normal(-0.7, 0.3, (D, S)))
             ampS, sigS = np.exp(rs.normal(0.0, 0.3, S)), np.exp(rs.normal(-3.0, 0.3, S))
             api.loglike_batch(X, y, KERNEL, lamS, ampS, sigS, device=dev)
@@ -682,7 +716,7 @@ def main():
         # acquisition over M candidates of the N=4096 posterior: the first call on a fresh factorisation (what one step of a BO
         # loop or one shard of configs[2] at G = 8192/M GPUs pays) and a later call on the same factorisation
         acq_by_m = {}
-        for M in (1024, 2048, 4096, 8192):
+        for M in ((1024, 2048, 4096, 8192) if not args.no_extras else ()):
             cm = api.Candidates(Xs[:, :M], device=dev)
             first, later = [], []
             for i in range(4):
@@ -717,6 +751,57 @@ def main():
                                                    "256-row substitution steps spread over the chip (few-candidates path)",
                                 "path_later_calls": "fused kernel" if M > 4096 else "resident inverse factors (two GEMMs, built on the second call)"}
             cm.close()
+
+    # ---- BASELINE configs[3]: semiparametric model (parametric mean + GP), 2 constrained outputs, N = 2048, d = 6, 8192 candidates
+    config4 = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        note("config 4 (two outputs, semiparametric)")
+        N4, D4, P4 = 2048, 6, 2
+        r4 = np.random.default_rng(3)
+        X4 = r4.uniform(0, 1, (D4, N4))
+        Xs4 = r4.uniform(0, 1, (D4, M_CAND))
+        th = np.array([[0.2, 0.3, -0.1, 0.0, 0.1, 0.2, -0.2], [-0.1, 0.1, 0.2, -0.3, 0.0, 0.1, 0.1]])      # m_p(x; θ) = θ_p0 + θ_p1..6 · x, evaluated on the host
+        mX4 = [th[p, 0] + th[p, 1:] @ X4 for p in range(P4)]
+        mXs4 = np.stack([th[p, 0] + th[p, 1:] @ Xs4 for p in range(P4)])
+        Y4 = np.stack([mX4[p] + np.sin(2 * np.pi * X4).sum(0) / np.sqrt(D4) * (1.0 - 0.5 * p) + 0.05 * r4.standard_normal(N4) for p in range(P4)])
+        g4 = [api.GP(X4, Y4[p], KERNEL, device=dev) for p in range(P4)]
+        c4 = api.Candidates(Xs4, device=dev)
+        lam4 = np.full(D4, 0.5)
+        ymax4 = [np.inf, 0.5]
+        feas = Y4[1] <= 0.5
+        best4 = float(Y4[0][feas].max()) if feas.any() else None
+
+        def upd_pair(i, nosync):
+            for p in range(P4):
+                g4[p].update(lam4, 1.0, 0.05 + 1e-4 * (i % 7), mean_X=mX4[p], sync=not nosync)
+            if nosync:
+                for p in range(P4):
+                    g4[p].sync()
+        res4 = {}
+        for nosync in (False, True):
+            tu, ta = [], []
+            for i in range(12):
+                t0 = time.perf_counter()
+                upd_pair(i, nosync)
+                t1 = time.perf_counter()
+                _, am4, mx4 = api.acq_ei([g4], c4, [1.0, 0.0], ymax4, best4, mean_Xs=mXs4[None], want_acq=False)
+                t2 = time.perf_counter()
+                tu.append(t1 - t0)
+                ta.append(t2 - t1)
+            res4["enqueued_back_to_back" if nosync else "one_after_the_other"] = {
+                "ms_two_output_update": float(np.median(tu[2:])) * 1e3, "ms_ei_times_feasibility_pass": float(np.median(ta[2:])) * 1e3}
+        tu = res4["enqueued_back_to_back"]["ms_two_output_update"] * 1e-3
+        ta = res4["enqueued_back_to_back"]["ms_ei_times_feasibility_pass"] * 1e-3
+        config4 = {"workload": "Semiparametric (parametric mean + GP), P = 2 outputs (y_max = [Inf, 0.5]), N = 2048, d = 6, 8192 candidates; mean vectors evaluated on the host",
+                   **res4, "two_output_updates_per_sec": 1.0 / tu, "acq_evals_per_sec": M_CAND / ta,
+                   "update_frac_of_fp64_mfma_peak": P4 * flops_update(N4, D4) / tu / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                   "acq_frac_of_fp64_mfma_peak": P4 * M_CAND * flops_acq_eval(N4, D4) / ta / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                   "argmax": [int(am4), float(mx4)],
+                   "note": "the two outputs' factorisations share one context (one resident chain): enqueued back to back (BOSS_FIT_NO_SYNC) the second "
+                           "starts behind the first without a host round trip; they do not overlap"}
+        c4.close()
+        for g in g4:
+            g.close()
 
     # ---- configs[2] through the one-process multi-GPU entry points (a fresh child process: this one stays alive and idle meanwhile)
     inproc = None
@@ -772,7 +857,7 @@ def main():
             "frac_of_fp64_mfma_roofline": {"update": flops_update(N_OBS, D) * upd_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12),
                                            "acq": flops_acq_eval(N_OBS, D) * acq_rate / world / (FP64_MFMA_PEAK_TFLOPS * 1e12)},
             "roofline": roof, "roofline_potrf": roof_potrf, "update_latency": upd_dist, "strong_scaling": strong, "strong_scaling_inproc": inproc,
-            "batched_updates": batched, "acq_by_M": acq_by_m, "cpu_baseline": cpu, "next_rows": extras,
+            "batched_updates": batched, "acq_by_M": acq_by_m, "config4": config4, "cpu_baseline": cpu, "next_rows": extras,
             # BASELINE config 5 end to end (also inside batched_updates, next to the bare batched likelihood it is compared with)
             "config5_acq_S512": (batched or {}).get("config5_acq_S512"),
         }
