@@ -295,6 +295,113 @@ __global__ __launch_bounds__(256) void grad_accum_kernel(const double* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// ∇μ, ∇σ² of a gradient-observation posterior (GradientGaussianProcess, src/models/gradient_gp.jl:334-361 under the ForwardDiff of
+// OptimizationAM, src/acquisition_maximizers/optimization.jl:36,89-118).  Rows of the n(1+d) system: (l, point i), l = 0 the value.
+// With t = (x* − x_i) ⊘ λ², h = κ'(r)/r, g = h'(r)/r:
+//     ∇_{x*} k*_(i,0) = α² h t ,      ∇_{x*} k*_(i,l) = −α² (g t_l t + h e_l / λ_l²)          (l >= 1)
+// so per point   ∇μ += α² [ t (h a_i0 − g Σ_l a_il t_l) − h (a_i· ⊘ λ²) ]   and the same with w for −½ ∇σ².
+// The derivative rows are evaluated at x_i + 1e-8 when x* ≈ x_i (aug_entry, _build_cross_cov :233).
+// One workgroup per 32-candidate slab and row split: lanes along the candidates, eight point subsets; the a entries come from avec
+// (row l·n + i), the w entries from the W slabs.  part (gridDim.y > 1): [tile·gridDim.y + y][2 d][32], summed by aug_grad_finalize_kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aug_grad_accum_kernel(const double* __restrict__ Wslabs, const double* __restrict__ avec, int Np,
+                                                             int n, const double* __restrict__ Xraw, int ldx,
+                                                             const double* __restrict__ Craw, int d, int Mp, int M, int kern,
+                                                             double amp2, const double* __restrict__ invlam,
+                                                             double* __restrict__ dmu, double* __restrict__ dvar,
+                                                             double* __restrict__ part) {
+    constexpr int BN = 32, DM = AUG_MAX_D;
+    __shared__ double red[8][2 * DM][BN];
+    const int tid = threadIdx.x, c = tid & 31, rs = tid >> 5;
+    const int j = blockIdx.x * BN + c;
+    const double* W = Wslabs + (size_t)blockIdx.x * Np * BN + c;
+    double xc[DM], il2[DM], il[DM], G1[DM], G2[DM];
+    double nc = 0.0;
+#pragma unroll
+    for (int m = 0; m < DM; ++m) {
+        xc[m] = m < d ? Craw[(size_t)m * Mp + j] : 0.0;
+        il[m] = m < d ? invlam[m] : 0.0;
+        il2[m] = il[m] * il[m];
+        nc = __builtin_fma(xc[m], xc[m], nc);
+        G1[m] = G2[m] = 0.0;
+    }
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int ibeg = blockIdx.y * per, iend = min(n, ibeg + per);
+    for (int i = ibeg + rs; i < iend; i += 8) {
+        double t[DM], du2 = 0.0, ni = 0.0, r2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            const double x = m < d ? Xraw[(size_t)m * ldx + i] : 0.0;
+            const double u = xc[m] - x;
+            du2 = __builtin_fma(u, u, du2);
+            ni = __builtin_fma(x, x, ni);
+            t[m] = u;
+        }
+#pragma unroll
+        for (int m = 0; m < DM; ++m) r2 = __builtin_fma(t[m] * il[m], t[m] * il[m], r2);
+        const double a0 = avec[i], w0 = W[(size_t)i * BN];
+        const double h0 = kappa_prime_over_r_r2(kern, r2);   // the value row: at the points as given
+        double rr2 = r2;
+        if (du2 <= ISAPPROX_RTOL2 * fmax(nc, ni)) {          // x* ≈ x_i: the derivative rows at x_i + 1e-8
+            rr2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < DM; ++m) {
+                if (m < d) t[m] -= MIN_PARAM_VALUE;
+                rr2 = __builtin_fma(t[m] * il[m], t[m] * il[m], rr2);
+            }
+        }
+        const double h = kappa_prime_over_r_r2(kern, rr2), g = kappa_second_r2(kern, rr2);
+        double sa = 0.0, sw = 0.0, al[DM], wl[DM];
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            al[m] = m < d ? avec[(size_t)(m + 1) * n + i] : 0.0;
+            wl[m] = m < d ? W[((size_t)(m + 1) * n + i) * BN] : 0.0;
+            const double tm = t[m] * il2[m];
+            sa = __builtin_fma(al[m], tm, sa);
+            sw = __builtin_fma(wl[m], tm, sw);
+        }
+        // (the value row's t is the unshifted one: its shift only matters where t ≈ 0 anyway)
+        const double ka = -g * sa, kw = -g * sw;
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            const double tm = t[m] * il2[m];
+            const double tm0 = (du2 <= ISAPPROX_RTOL2 * fmax(nc, ni)) ? (t[m] + (m < d ? MIN_PARAM_VALUE : 0.0)) * il2[m] : tm;
+            G1[m] += tm0 * h0 * a0 + tm * ka - h * al[m] * il2[m];
+            G2[m] += tm0 * h0 * w0 + tm * kw - h * wl[m] * il2[m];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < DM; ++m) {
+        red[rs][2 * m][c] = G1[m];
+        red[rs][2 * m + 1][c] = G2[m];
+    }
+    __syncthreads();
+    for (int slot = rs; slot < 2 * d; slot += 8) {
+        double v = 0.0;
+        for (int k = 0; k < 8; ++k) v += red[k][slot][c];
+        const int m = slot >> 1;
+        if (gridDim.y > 1) part[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * DM + slot) * BN + c] = v;
+        else if (j < M) {
+            if (slot & 1) dvar[(size_t)j * d + m] = -2.0 * amp2 * v;
+            else dmu[(size_t)j * d + m] = amp2 * v;
+        }
+    }
+}
+__global__ __launch_bounds__(32) void aug_grad_finalize_kernel(const double* __restrict__ part, int rsplit, int d, int M, double amp2,
+                                                               double* __restrict__ dmu, double* __restrict__ dvar) {
+    constexpr int BN = 32, DM = AUG_MAX_D;
+    const int c = threadIdx.x, j = blockIdx.x * BN + c;
+    if (j >= M) return;
+    for (int slot = 0; slot < 2 * d; ++slot) {
+        double v = 0.0;
+        for (int y = 0; y < rsplit; ++y) v += part[(((size_t)blockIdx.x * rsplit + y) * 2 * DM + slot) * BN + c];
+        const int m = slot >> 1;
+        if (slot & 1) dvar[(size_t)j * d + m] = -2.0 * amp2 * v;
+        else dmu[(size_t)j * d + m] = amp2 * v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Tracked candidates (boss_track_t): the V = L⁻¹K* slabs of a fixed candidate set stay resident, so
 // after boss_gp_append the predictive moments are UPDATED instead of re-solved — per new observation
 // r one more row of V,   v_r = (k(x_r, x*) − Σ_{i<r} L[r,i] V[i,·]) / L[r,r] ,   σ² −= v_r² ,  μ += v_r z_r ,

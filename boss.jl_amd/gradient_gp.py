@@ -79,7 +79,7 @@ class HipGradientGPPosteriorSlice(HipGaussianProcessPosteriorSlice):
     def _unavailable(self, *a, **k):
         raise NotImplementedError("not defined for gradient-observation posteriors")
 
-    mean_and_var_grad = mean_and_cov = cov = append = _unavailable
+    mean_and_cov = cov = append = _unavailable               # (mean_and_var_grad: inherited — boss_gp_predict_grad takes these posteriors)
 
 
 @dataclass

@@ -577,7 +577,8 @@ the acquisition from `multistart` starts inside the domain, the best local optim
 src/utils/optim_multistart.jl).  The reference differentiates the acquisition with ForwardDiff (:36) one start at a time; here
 the gradient is analytic and evaluated on the device for ALL starts in one call per iteration (`boss_acq_ei_grad`): projected
 gradient ascent with a per-start step and backtracking.  Discrete dimensions are rounded (gradient 0); `cons` is honoured through
-make_safe (acq = 0 outside) and a final in-domain filter.
+make_safe (acq = 0 outside) and a final in-domain filter.  Works on `HipGaussianProcess` / `HipSemiparametric` posteriors and on those of
+`HipGradientGaussianProcess` (`boss_acq_ei_grad` differentiates the augmented cross-covariances of src/models/gradient_gp.jl:221-243 as well).
 """
 Base.@kwdef struct HipGradientAM <: BOSS.AcquisitionMaximizer
     multistart::Union{Int, Matrix{Float64}} = 200        # number of starts, or the starts as columns (set_starts, optimization.jl:43-52)

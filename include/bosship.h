@@ -144,9 +144,11 @@ int boss_gp_get_factor(const boss_gp_t* gp, double* L_out, double* z_out);
  * The model's mean function is not used by the reference for this model and is not taken here.
  * The returned handle is a boss_gp_t: boss_gp_sync, boss_gp_predict (mu = k*'alpha, var = max(0, k(x,x) - |L^-1 k*|^2),
  * k* from _build_cross_cov :221-243; mean_Xs must be NULL), boss_gp_get_factor, boss_acq_ei, boss_acq_ei_moments
- * and boss_gp_free work on it; the entry points that assume value-only observations (boss_gp_update,
- * boss_gp_set_y, boss_gp_append, boss_gp_reserve, boss_gp_predict_grad, boss_gp_predict_cov,
- * boss_gp_loglike_grad, boss_acq_ei_grad, boss_track_create) return BOSS_E_INVALID.
+ * boss_gp_predict_grad and boss_acq_ei_grad (the gradients ForwardDiff pushes through :334-361 inside OptimizationAM,
+ * src/acquisition_maximizers/optimization.jl:36,89-118; mean_Xs / mean_grad must be NULL; var is max(0, .), its gradient that of
+ * the unclipped expression) and boss_gp_free work on it; the entry points that assume value-only observations (boss_gp_update,
+ * boss_gp_set_y, boss_gp_append, boss_gp_reserve, boss_gp_predict_cov, boss_gp_loglike_grad, boss_track_create) return
+ * BOSS_E_INVALID.
  * Limits: d <= 16, n(1+d) <= 46080. */
 int boss_ggp_create(int device, int kernel, int d, int n, const double* X, const double* y, const double* dY,
                     boss_gp_t** out);

@@ -771,6 +771,50 @@ def gradient_gp_mean_and_var(post: GradientGPPosterior, Xs):
     return mu, np.maximum(0.0, amp2 - np.sum(V * V, axis=0))
 
 
+def gradient_gp_mean_and_var_grad(post: "GradientGPPosterior", Xs):
+    """What ForwardDiff yields when OptimizationAM differentiates the acquisition through a GradientGaussianProcess posterior
+    (src/acquisition_maximizers/optimization.jl:36,89-118 through src/models/gradient_gp.jl:334-361): the moments of
+    `gradient_gp_mean_and_var` (variance UNclipped here) and their gradients w.r.t. the candidate columns,
+        ∇μ = Σ_rows α_row ∇k*_row ,   ∇σ² = −2 Σ_rows w_row ∇k*_row ,  w = K⁻¹k* ,
+    with, for t = (x* − x_j) ⊘ λ², h = κ'(r)/r, g = h'(r)/r:
+        value row j:        ∇_{x*} k(x*, x_j)              = α² h t
+        derivative row (j, l):  ∇_{x*} ∂k(x*, x_j)/∂(x_j)_l = −α² (g t_l t + h e_l/λ_l²)
+    (the derivative rows at x_j + 1e-8 when x* ≈ x_j, as `_build_cross_cov` evaluates them).  No reference test covers this
+    (PARITY UNPINNED beyond the finite differences of tests/test_oracle_crosscheck.py).
+    Returns (mu[M], var[M], dmu[d, M], dvar[d, M])."""
+    kernel = KERNEL_NAMES.get(post.kernel, post.kernel) if isinstance(post.kernel, str) else post.kernel
+    X = np.asarray(post.X, dtype=np.float64)
+    Xs = np.asarray(Xs, dtype=np.float64)
+    if Xs.ndim == 1:
+        Xs = Xs[:, None]
+    d, n = X.shape
+    M = Xs.shape[1]
+    lam = np.asarray(post.lengthscale, dtype=np.float64) + MIN_PARAM_VALUE
+    amp2 = (float(post.amplitude) + MIN_PARAM_VALUE) ** 2
+    Ks = augmented_cross_cov(post.kernel, X, post.lengthscale, post.amplitude, Xs)
+    mu = Ks.T @ post.alpha
+    V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
+    W = sla.solve_triangular(post.L, V, lower=True, trans="T", check_finite=False)
+    var = amp2 - np.sum(V * V, axis=0)
+    dmu, dvar = np.zeros((d, M)), np.zeros((d, M))
+    for c in range(M):
+        for j in range(n):
+            xs, xj = Xs[:, c], X[:, j]
+            u0 = xs - xj
+            r0 = float(np.sqrt(np.sum((u0 / lam) ** 2)))
+            gk = amp2 * float(kappa_prime_over_r(kernel, np.float64(r0))) * (u0 / lam ** 2)          # value row (as given)
+            u = xs - (xj + MIN_PARAM_VALUE) if _isapprox(xs, xj) else u0
+            r = float(np.sqrt(np.sum((u / lam) ** 2)))
+            h = float(kappa_prime_over_r(kernel, np.float64(r)))
+            g = float(kappa_second(kernel, np.float64(r)))
+            t = u / lam ** 2
+            rows = n + np.arange(d) * n + j
+            J = -amp2 * (g * np.outer(t, t) + h * np.diag(1.0 / lam ** 2))                            # J[l, m] = ∂(row l)/∂x*_m
+            dmu[:, c] += post.alpha[j] * gk + J.T @ post.alpha[rows]
+            dvar[:, c] += -2.0 * (W[j, c] * gk + J.T @ W[rows, c])
+    return mu, var, dmu, dvar
+
+
 # ------------------------------------------------------------------------------------------
 # NonstationaryGP (SURVEY §8f4): src/models/nonstationary_gp/nonstationary_gp.jl.  λ(·), α(·), σ(·) are
 # functions of the input (posteriors of latent ParametrizedGPs, or constants, :198-212); here they arrive

@@ -1659,7 +1659,7 @@ def test_gradient_gp_errors_and_unsupported_entry_points(api, O):
         g.update([0.5, 0.5], 1.0, 0.1, -1.0)
     g.update([0.5, 0.5], 1.0, 0.1, 0.1)
     for call in (lambda: api.GP.update(g, [0.5, 0.5], 1.0, 0.1), lambda: g.set_y(y), lambda: g.append(X[:, :1], y[:1]),
-                 lambda: g.reserve(100), lambda: g.predict_grad(X), lambda: g.predict_cov(X), lambda: g.loglike_grad(),
+                 lambda: g.reserve(100), lambda: g.predict_grad(X, np.zeros(n)), lambda: g.predict_cov(X), lambda: g.loglike_grad(),
                  lambda: g.predict(X, np.zeros(n)), lambda: api.Track(g, api.Candidates(X))):
         with pytest.raises(api.BossError):
             call()
@@ -1674,6 +1674,43 @@ def test_gradient_gp_errors_and_unsupported_entry_points(api, O):
     with pytest.raises(api.PosDefException):
         gd.update([0.5, 0.5], 1.0, 0.0, 0.0)
     gd.close()
+    g.close()
+
+
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+@pytest.mark.parametrize("d,n,M", [(1, 5, 3), (3, 40, 70), (8, 150, 40), (16, 70, 33), (4, 300, 1100)])
+def test_gradient_gp_candidate_gradients(api, O, kernel, d, n, M):
+    """SURVEY §8f3 over §8f4: ∇μ, ∇σ² and ∇acq of a gradient-observation posterior — what ForwardDiff pushes through
+    mean_and_var (src/models/gradient_gp.jl:334-361) inside OptimizationAM (src/acquisition_maximizers/optimization.jl:36,89-118).
+    Against the oracle's analytic gradients (themselves checked against finite differences, tests/test_oracle_crosscheck.py)."""
+    X, y, dY = make_grad(d, n, seed=d + n)
+    lam = np.linspace(0.35, 0.6, d)
+    post = O.gradient_gp_fit(X, y, dY, kernel, lam, 1.1, 1e-2, 3e-2)
+    Xs = np.random.default_rng(M).uniform(0.05, 0.95, (d, M))
+    mu_o, var_o, dmu_o, dvar_o = O.gradient_gp_mean_and_var_grad(post, Xs)
+    g = api.GradGP(X, y, dY, kernel)
+    g.update(lam, 1.1, 1e-2, 3e-2)
+    mu, var, dmu, dvar = g.predict_grad(Xs)
+    K = O.augmented_kernel_matrix(kernel, X, lam, 1.1, 1e-2, 3e-2)
+    tol = max(1e-9, np.linalg.cond(K) * K.shape[0] * 2.0 ** -53 * 8)
+    sc = 1 + np.abs(dmu_o).max()
+    assert np.all(np.abs(mu - mu_o) <= tol * (1 + np.abs(mu_o)))
+    assert np.all(np.abs(var - np.maximum(var_o, 0.0)) <= tol * 1.1 ** 2)
+    assert np.abs(dmu - dmu_o).max() <= tol * sc * 10, np.abs(dmu - dmu_o).max()
+    assert np.abs(dvar - dvar_o).max() <= tol * (1 + np.abs(dvar_o).max()) * 10, np.abs(dvar - dvar_o).max()
+    # the acquisition's chain rule on the device from those moments (construct_ei, expected_improvement.jl:74-76)
+    best = float(y.max()) - 0.3
+    acq, dacq = api.acq_ei_grad([g], Xs, [1.0], None, best)
+    vo = np.maximum(var_o, 0.0)
+    acq_o, dacq_o = O.expected_improvement_lin_grad([1.0], mu_o[None], vo[None], dmu_o[None], np.where(vo > 0, dvar_o, 0.0)[None], best)
+    assert np.all(np.abs(acq - acq_o) <= tol * 10)
+    assert np.abs(dacq - dacq_o).max() <= tol * (1 + np.abs(dacq_o).max()) * 100, np.abs(dacq - dacq_o).max()
+    # repeated (the second few-candidates call on a factorisation runs on the resident inverse factors: another summation order);
+    # the plain prediction still agrees
+    mu2, var2, dmu2, dvar2 = g.predict_grad(Xs)
+    assert np.abs(dmu2 - dmu).max() <= tol * sc * 10 and np.abs(dvar2 - dvar).max() <= tol * (1 + np.abs(dvar_o).max()) * 10
+    mu3, var3 = g.predict(Xs)
+    assert np.all(np.abs(mu3 - mu) <= 1e-9 * (1 + np.abs(mu)))
     g.close()
 
 
@@ -1715,6 +1752,18 @@ def test_gradient_gp_acquisition_and_host_mirror(api, O):
     for mode in ("candidates", "outputs", "samples"):
         x, val = B.HipBatchAM(points=Xs, shard=mode).maximize_acquisition(prob)
         assert np.array_equal(x, Xs[:, int(np.argmax(want))]) and abs(val - want.max()) <= 1e-10, mode
+    # OptimizationAM semantics on gradient posteriors (optimization.jl:89-118 through gradient_gp.jl:334-361): multistart ascent on
+    # the device gradients ends at a point of the domain that is at least as good as the best of its starts
+    gam = B.HipGradientAM(x_prior=lambda r: r.uniform(0, 1, d), multistart=40, iters=15, seed=5)
+    xg, vg = gam.maximize_acquisition(prob)
+    starts = np.stack([np.random.default_rng(5).uniform(0, 1, d)], axis=1)
+    pp = model.model_posterior(prm, data)
+    a0, _, _ = api.acq_ei([[s.gp for s in p.slices] for p in pp], api.Candidates(np.asfortranarray(starts)), coefs, y_max, b, None)
+    mg, vgrad, dmg, dvg = pp[0].slices[0].mean_and_var_grad(starts)
+    assert dmg.shape == (d, 1) and np.isfinite(dmg).all()
+    for p in pp:
+        p.close()
+    assert np.all(xg >= 0) and np.all(xg <= 1) and vg >= a0[0] - 1e-12
     ll = model.data_loglike(data)
     assert abs(ll(prm[0]) - sum(o.logpdf for o in oposts[0])) <= 1e-9 * (1 + abs(sum(o.logpdf for o in oposts[0])))
     assert np.allclose(model.data_loglike_batch(data, prm), [sum(o.logpdf for o in op) for op in oposts], rtol=1e-9)

@@ -298,3 +298,36 @@ def test_gibbs_kernel_is_positive_definite_and_symmetric_for_varying_lengthscale
         s = lam[i, 3] ** 2 + lam[i, 7] ** 2
         k *= np.sqrt(2 * lam[i, 3] * lam[i, 7] / s) * np.exp(-(X[i, 3] - X[i, 7]) ** 2 / s)
     assert abs(K[3, 7] - k) <= 1e-15
+
+
+def test_gradient_gp_candidate_gradients_match_finite_differences():
+    """oracle.gradient_gp_mean_and_var_grad (the analytic ∇μ, ∇σ² of a GradientGaussianProcess posterior,
+    /root/reference/src/models/gradient_gp.jl:334-361 under the automatic differentiation of
+    src/acquisition_maximizers/optimization.jl:36) against central differences of gradient_gp_mean_and_var's formulas."""
+    import scipy.linalg as sla
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(0)
+    for kern in ("matern32", "matern52", "sqexp"):
+        d, n, M = 3, 12, 5
+        X = rng.uniform(0, 1, (d, n))
+        w = np.linspace(1, 2, d)[:, None]
+        y = np.sin(2 * np.pi * w * X).sum(0)
+        dY = 2 * np.pi * w * np.cos(2 * np.pi * w * X)
+        post = O.gradient_gp_fit(X, y, dY, kern, np.array([0.4, 0.5, 0.6]), 1.2, 1e-2, 2e-2)
+        Xs = rng.uniform(0, 1, (d, M))
+        mu, var, dmu, dvar = O.gradient_gp_mean_and_var_grad(post, Xs)
+        mu0, var0 = O.gradient_gp_mean_and_var(post, Xs)
+        assert np.allclose(mu, mu0, rtol=0, atol=1e-12) and np.allclose(np.maximum(var, 0), var0, rtol=0, atol=1e-12)
+
+        def f(Z):
+            Ks = O.augmented_cross_cov(post.kernel, post.X, post.lengthscale, post.amplitude, Z)
+            V = sla.solve_triangular(post.L, Ks, lower=True)
+            return Ks.T @ post.alpha, (post.amplitude + 1e-8) ** 2 - np.sum(V * V, axis=0)
+        e = 1e-6
+        for m in range(d):
+            Zp, Zm = Xs.copy(), Xs.copy()
+            Zp[m] += e
+            Zm[m] -= e
+            (mp, vp), (mm, vm) = f(Zp), f(Zm)
+            assert np.abs((mp - mm) / (2 * e) - dmu[m]).max() <= 1e-6 * (1 + np.abs(dmu[m]).max())
+            assert np.abs((vp - vm) / (2 * e) - dvar[m]).max() <= 1e-6 * (1 + np.abs(dvar[m]).max())
