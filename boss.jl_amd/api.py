@@ -67,6 +67,10 @@ SIGNATURES = {
                                      C.POINTER(C.c_int)]),
     "boss_acq_ei_moments": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
                                       C.c_double, _c_ucp, _c_dp, C.POINTER(C.c_long), _c_dp]),
+    "boss_ngp_predict_grad": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
+                                        C.POINTER(C.c_long)]),
+    "boss_acq_ei_grad_moments": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
+                                           C.c_double, _c_ucp, _c_dp, _c_dp]),
     "boss_acq_ei_grad": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.c_int,
                                    C.c_double, _c_ucp, _c_dp, _c_dp]),
     "boss_track_create": (C.c_int, [C.c_void_p, C.c_void_p, _c_dp, C.POINTER(C.c_void_p)]),
@@ -469,6 +473,33 @@ class GibbsGP(GP):
         _check(rc)
         return mu, var
 
+    def predict_grad(self, Xs, lam_Xs, amp_Xs, dlam_Xs=None, damp_Xs=None, mean_Xs=None, mean_grad=None):
+        """mean_and_var and its gradient w.r.t. the candidates (boss_ngp_predict_grad): dlam_Xs d×d×M with [l, m, j] = ∂λ_l/∂x_m at
+        candidate j (None: constant λ), damp_Xs d×M (None: constant α).  Returns (mu[M], var[M], dmu[d,M], dvar[d,M])."""
+        Xs = _f64(Xs)
+        if Xs.ndim == 1:
+            Xs = _f64(Xs.reshape(-1, 1))
+        M = Xs.shape[1]
+        lam = _f64(np.asarray(lam_Xs, dtype=np.float64).reshape(self.d, M), 2)
+        amp = _f64(np.asarray(amp_Xs).reshape(-1), 1)
+        if Xs.shape[0] != self.d or amp.shape[0] != M:
+            raise ValueError("candidates must be d×M with lam_Xs d×M and amp_Xs M")
+        dl = None if dlam_Xs is None else np.asfortranarray(np.asarray(dlam_Xs, dtype=np.float64).reshape(self.d, self.d, M))
+        da = None if damp_Xs is None else _f64(np.asarray(damp_Xs, dtype=np.float64).reshape(self.d, M), 2)
+        ms = None if mean_Xs is None else _f64(np.asarray(mean_Xs).reshape(-1), 1)
+        mg = None if mean_grad is None else _f64(np.asarray(mean_grad, dtype=np.float64).reshape(self.d, M), 2)
+        mu, var = np.zeros(M), np.zeros(M)
+        dmu, dvar = np.zeros((self.d, M), order="F"), np.zeros((self.d, M), order="F")
+        bad = C.c_long(-1)
+        rc = load_library().boss_ngp_predict_grad(self._h, M, _dp(Xs), _dp(lam), _dp(amp), _dp(dl), _dp(da), _dp(ms), _dp(mg), _dp(mu),
+                                                  _dp(var), _dp(dmu), _dp(dvar), C.byref(bad))
+        if rc == BOSS_E_NEG_VAR:
+            e = DomainError(rc, load_library().boss_last_error().decode())
+            e.bad_index = bad.value
+            raise e
+        _check(rc)
+        return mu, var, dmu, dvar
+
 
 class Candidates:
     """A resident batch of candidate points (boss_cand_t)."""
@@ -630,6 +661,28 @@ def acq_ei(gps: Sequence[Sequence[GP]], cand: Candidates, fit_coefs, y_max=None,
                                       0.0 if best is None else float(best), _ucp(mask), _dp(acq), C.byref(am),
                                       C.byref(mx)))
     return acq, am.value, mx.value
+
+
+def acq_ei_grad_moments(mu, var, dmu, dvar, fit_coefs, y_max=None, best=None, valid_mask=None, device: int = 0):
+    """EI × feasibility and its gradient w.r.t. the candidates from moments and moment gradients already on the host
+    (boss_acq_ei_grad_moments): mu / var [P][M], dmu / dvar [P][d][M].  Returns (acq[M], dacq[d, M])."""
+    mu = _f64(np.atleast_2d(mu), 2)
+    var = _f64(np.atleast_2d(var), 2)
+    P, M = mu.shape
+    gm = np.asarray(dmu, dtype=np.float64).reshape(P, -1, M)
+    gv = np.asarray(dvar, dtype=np.float64).reshape(P, -1, M)
+    d = gm.shape[1]
+    gm = np.ascontiguousarray(gm.transpose(0, 2, 1))          # [p][j*d + m]
+    gv = np.ascontiguousarray(gv.transpose(0, 2, 1))
+    coefs = _f64(np.asarray(fit_coefs).reshape(-1), 1)
+    ym = None if y_max is None else _f64(np.asarray(y_max).reshape(-1), 1)
+    mask = None if valid_mask is None else np.ascontiguousarray(np.asarray(valid_mask, dtype=bool).astype(np.uint8))
+    acq = np.zeros(M)
+    dacq = np.zeros((d, M), order="F")
+    _check(load_library().boss_acq_ei_grad_moments(device, P, M, d, _dp(mu), _dp(var), _dp(gm), _dp(gv), _dp(coefs), _dp(ym),
+                                                   0 if best is None else 1, 0.0 if best is None else float(best), _ucp(mask), _dp(acq),
+                                                   _dp(dacq)))
+    return acq, dacq
 
 
 class Track:

@@ -402,6 +402,89 @@ __global__ __launch_bounds__(32) void aug_grad_finalize_kernel(const double* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// Candidate gradients of a nonstationary posterior (Gibbs kernel, src/models/nonstationary_gp/nonstationary_gp.jl:61-107,153-196):
+// the candidate enters k_i = k(x_i, x*) directly and through λ(x*), α(x*).  With q_l = λ_il² + λ*_l², Δ_l = x_il − x*_l:
+//     e_l = ∂ln k_i/∂x*_l = 2 Δ_l/q_l ,   c_l = ∂ln k_i/∂λ*_l = ½ (1/λ*_l − 2 λ*_l/q_l) + 2 λ*_l Δ_l²/q_l² ,   s = ∂ln k_i/∂α* = 2/(α_i + α*)
+// The kernel leaves, per candidate, the sums Σ_i a_i k_i (s, e, c) and Σ_i w_i k_i (s, e, c) — sums[slot][Mp], slot = which·(2d+1) +
+// {0: s, 1+l: e_l, 1+d+l: c_l} — and the host folds the caller's Jacobians ∂λ/∂x, ∂α/∂x in (boss_ngp_predict_grad).
+// One workgroup per 32-candidate slab: lanes along the candidates, eight row subsets.  d <= 16.
+// ------------------------------------------------------------------------------------------
+constexpr int GIBBS_GRAD_MAX_D = 16;
+__global__ __launch_bounds__(256) void gibbs_grad_accum_kernel(const double* __restrict__ Wslabs, const double* __restrict__ avec, int Np,
+                                                               int N, const double* __restrict__ X, const double* __restrict__ Lam,
+                                                               const double* __restrict__ amp, const double* __restrict__ C,
+                                                               const double* __restrict__ Clam, const double* __restrict__ Camp, int d,
+                                                               int Mp, const unsigned char* __restrict__ discrete,
+                                                               double* __restrict__ sums) {
+    constexpr int BN = 32, DM = GIBBS_GRAD_MAX_D;
+    __shared__ double red[8][BN];
+    const int tid = threadIdx.x, c = tid & 31, rs = tid >> 5;
+    const int j = blockIdx.x * BN + c;
+    const double* W = Wslabs + (size_t)blockIdx.x * Np * BN + c;
+    double xc[DM], lc[DM], Ea[DM], Ca[DM], Ew[DM], Cw[DM], Sa = 0.0, Sw = 0.0;
+#pragma unroll
+    for (int m = 0; m < DM; ++m) {
+        xc[m] = m < d ? C[(size_t)m * Mp + j] : 0.0;
+        lc[m] = m < d ? Clam[(size_t)m * Mp + j] : 1.0;
+        Ea[m] = Ca[m] = Ew[m] = Cw[m] = 0.0;
+    }
+    const double ac = Camp[j];
+    for (int i = rs; i < N; i += 8) {
+        double prod = 1.0, esum = 0.0, e[DM], cl[DM];
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            if (m < d) {
+                const double x = X[(size_t)m * Np + i], l = Lam[(size_t)m * Np + i];
+                const double rq = rcp_refined(__builtin_fma(l, l, lc[m] * lc[m]));
+                const double df = x - xc[m];
+                prod *= 2.0 * l * lc[m] * rq;
+                esum = __builtin_fma(df * df, rq, esum);
+                e[m] = (discrete && discrete[m]) ? 0.0 : 2.0 * df * rq;
+                cl[m] = 0.5 * (1.0 / lc[m] - 2.0 * lc[m] * rq) + 2.0 * lc[m] * df * df * rq * rq;
+            } else {
+                e[m] = cl[m] = 0.0;
+            }
+        }
+        const double ai = amp[i], am = 0.5 * (ai + ac);
+        const double k = am * am * sqrt(prod) * exp(-esum);
+        const double wa = avec[i] * k, ww = W[(size_t)i * BN] * k, s = 1.0 / am;      // 2/(α_i + α*)
+        Sa = __builtin_fma(wa, s, Sa);
+        Sw = __builtin_fma(ww, s, Sw);
+#pragma unroll
+        for (int m = 0; m < DM; ++m) {
+            Ea[m] = __builtin_fma(wa, e[m], Ea[m]);
+            Ca[m] = __builtin_fma(wa, cl[m], Ca[m]);
+            Ew[m] = __builtin_fma(ww, e[m], Ew[m]);
+            Cw[m] = __builtin_fma(ww, cl[m], Cw[m]);
+        }
+    }
+    // the eight row subsets in order, slot by slot
+    const int nslot = 2 * d + 1;
+    auto reduce_store = [&](int slot, double v) {
+        __syncthreads();
+        red[rs][c] = v;
+        __syncthreads();
+        if (rs == 0) {
+            double t = red[0][c];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += red[q][c];
+            sums[(size_t)slot * Mp + j] = t;
+        }
+    };
+    reduce_store(0, Sa);
+    reduce_store(nslot, Sw);
+#pragma unroll
+    for (int m = 0; m < DM; ++m) {
+        if (m < d) {                                         // (uniform)
+            reduce_store(1 + m, Ea[m]);
+            reduce_store(1 + d + m, Ca[m]);
+            reduce_store(nslot + 1 + m, Ew[m]);
+            reduce_store(nslot + 1 + d + m, Cw[m]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Tracked candidates (boss_track_t): the V = L⁻¹K* slabs of a fixed candidate set stay resident, so
 // after boss_gp_append the predictive moments are UPDATED instead of re-solved — per new observation
 // r one more row of V,   v_r = (k(x_r, x*) − Σ_{i<r} L[r,i] V[i,·]) / L[r,r] ,   σ² −= v_r² ,  μ += v_r z_r ,

@@ -1,5 +1,5 @@
 module BOSSHip
-using BOSS, LinearAlgebra
+using BOSS, LinearAlgebra, ForwardDiff
 import BOSS: model_posterior_slice, data_loglike, params_loglike, _params_sampler, vectorizer, bijector,
              sliceable, slice, join_slices, make_discrete, mean, var, mean_and_var,
              estimate_parameters, maximize_acquisition
@@ -743,6 +743,38 @@ function mean_and_var_grad(post::HipPosteriorSlice, X::AbstractMatrix{<:Real}; m
         (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}),
         post.h.h, M, Xs, mean_vals(post.mean, Xs), mean_grad, μ, σ2, dμ, dσ2, bad))
     return μ, σ2, dμ, dσ2
+end
+"""
+The same for a nonstationary posterior: the candidate enters the Gibbs kernel directly and through λ(x*), α(x*); the Jacobians of the
+latent models (BOSS's own ParametrizedGP posteriors or constants, host closures) come from ForwardDiff — what OptimizationAM's AD
+(src/acquisition_maximizers/optimization.jl:36) would push through them — and everything over the N observations runs on the device.
+"""
+function mean_and_var_grad(p::HipNonstationaryPosterior, X::AbstractMatrix{<:Real}; mean_grad = C_NULL)
+    Xs = Matrix{Float64}(X); Xr = rounded(Xs, p.discrete); d, M = size(Xs)
+    λ = reduce(hcat, p.f_λ.(eachcol(Xr))); α = Float64.(p.f_α.(eachcol(Xr)))
+    Dλ = Array{Float64}(undef, d, d, M); Dα = Matrix{Float64}(undef, d, M)
+    for (j, x) in enumerate(eachcol(Xr))
+        Dλ[:, :, j] .= ForwardDiff.jacobian(p.f_λ, collect(x)); Dα[:, j] .= ForwardDiff.gradient(p.f_α, collect(x))
+    end
+    isnothing(p.discrete) || (Dλ[:, p.discrete, :] .= 0.0; Dα[p.discrete, :] .= 0.0)      # rounded dimensions: piecewise constant
+    μ = Vector{Float64}(undef, M); σ2 = similar(μ); dμ = Matrix{Float64}(undef, d, M); dσ2 = similar(dμ); bad = Ref{Clong}(-1)
+    check(ccall((:boss_ngp_predict_grad, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+         Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Clong}),
+        p.post.h.h, M, Xs, λ, α, Dλ, Dα, mean_vals(p.post.mean, Xs), mean_grad, μ, σ2, dμ, dσ2, bad))
+    return μ, σ2, dμ, dσ2
+end
+"EI × feasibility and its gradient w.r.t. the candidates from per-output moments and gradients (P-vectors of what `mean_and_var_grad` returns)."
+function acq_grad_from_moments(problem::BOSS.BossProblem, xs::AbstractMatrix{Float64}, moms::AbstractVector; device = 0)
+    d, M = size(xs); P = length(moms); coefs, ymax, hb, b, mask = ei_arguments(problem, xs)
+    mu = reduce(hcat, (m[1] for m in moms)); var = reduce(hcat, (max.(m[2], 0.0) for m in moms))      # M×P = [p][M]
+    dmu = cat((m[3] for m in moms)...; dims = 3); dvar = cat((m[4] for m in moms)...; dims = 3)        # d×M×P = [p][d×M]
+    acq = Vector{Float64}(undef, M); dacq = Matrix{Float64}(undef, d, M)
+    check(ccall((:boss_acq_ei_grad_moments, lib), Cint,
+        (Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble,
+         Ptr{UInt8}, Ptr{Cdouble}, Ptr{Cdouble}),
+        device, P, M, d, mu, var, dmu, dvar, coefs, ymax, hb, b, mask, acq, dacq))
+    return acq, dacq
 end
 "EI × feasibility and arg-max from moments the caller already holds (e.g. of a HipNonstationaryPosterior): mu, var are M×P×S arrays."
 function acq_from_moments(problem::BOSS.BossProblem, xs::AbstractMatrix{Float64}, mu::Array{Float64, 3}, var::Array{Float64, 3}; device = 0)

@@ -149,6 +149,33 @@ class HipNonstationaryPosteriorSlice:
         mu, var = self.gp.predict(X, _cols(self.f_lam, Xr).T, _cols(self.f_amp, Xr).reshape(-1), ms)
         return (float(mu[0]), float(var[0])) if vec else (mu, var)
 
+    def mean_and_var_grad(self, X, lam_jac: Optional[Callable] = None, amp_jac: Optional[Callable] = None, mean_grad=None,
+                          fd_step: float = 1e-6):
+        """mean_and_var and its gradient w.r.t. the candidate columns (boss_ngp_predict_grad) — what ForwardDiff pushes through the
+        posterior inside OptimizationAM (src/acquisition_maximizers/optimization.jl:36).  The candidate also enters through the latent
+        λ(x*), α(x*): `lam_jac(x) -> d×d` ([l, m] = ∂λ_l/∂x_m) and `amp_jac(x) -> d` supply their Jacobians; without them central
+        differences of the host closures are taken (step fd_step).  Returns (mu[M], var[M], dmu[d, M], dvar[d, M])."""
+        X = np.asarray(X, float)
+        if X.ndim == 1:
+            X = X[:, None]
+        d, M = X.shape
+        Xr = self._round(X)
+
+        def jac(f, x, n_out):
+            J = np.zeros((n_out, d))
+            for m in range(d):
+                e = np.zeros(d)
+                e[m] = fd_step
+                J[:, m] = (np.atleast_1d(np.asarray(f(x + e), float)) - np.atleast_1d(np.asarray(f(x - e), float))) / (2 * fd_step)
+            return J
+        Dl = np.stack([np.asarray(lam_jac(Xr[:, j]), float) if lam_jac else jac(self.f_lam, Xr[:, j], d) for j in range(M)], axis=2)
+        Da = np.stack([np.asarray(amp_jac(Xr[:, j]), float).reshape(-1) if amp_jac else jac(self.f_amp, Xr[:, j], 1)[0] for j in range(M)], axis=1)
+        if self.discrete is not None:                        # rounded dimensions: the latent models are piecewise constant in them
+            Dl[:, self.discrete, :] = 0.0
+            Da[self.discrete, :] = 0.0
+        ms = None if self.mean_fn is None else np.array([float(self.mean_fn(X[:, j])) for j in range(M)])
+        return self.gp.predict_grad(X, _cols(self.f_lam, Xr).T, _cols(self.f_amp, Xr).reshape(-1), Dl, Da, ms, mean_grad)
+
     def mean(self, x):
         return self.mean_and_var(x)[0]
 

@@ -167,7 +167,8 @@ int boss_ggp_update(boss_gp_t* gp, const double* lengthscale, double amplitude, 
  *   then be evaluated at the rounded points as well.  No 1e-8 is added to these parameters (the reference adds none).
  * boss_ngp_update factorises and returns logpdf(FiniteGP, y); boss_ngp_predict is mean_and_var with _clip_var
  * (k(x*,x*) = a(x*)^2, +1e-18 jitter as for the plain model).  boss_gp_sync, boss_gp_set_y, boss_gp_get_factor,
- * boss_gp_free and boss_acq_ei_moments (EI on the predicted moments) work with these handles; the other
+ * boss_gp_free, boss_acq_ei_moments (EI on the predicted moments), boss_ngp_predict_grad and boss_acq_ei_grad_moments (their
+ * gradients w.r.t. the candidates) work with these handles; the other
  * boss_gp_* / boss_acq_* / boss_track_* entry points return BOSS_E_INVALID for them. */
 int boss_ngp_create(int device, int d, int N, const double* X, const double* y, const unsigned char* discrete,
                     boss_gp_t** out);
@@ -175,6 +176,18 @@ int boss_ngp_update(boss_gp_t* gp, const double* lam_X, const double* amp_X, con
                     const double* mean_X, int flags, double* logpdf_out);
 int boss_ngp_predict(boss_gp_t* gp, int M, const double* Xs, const double* lam_Xs, const double* amp_Xs,
                      const double* mean_Xs, double* mu, double* var, long* bad_index);
+/* mean_and_var of a nonstationary posterior AND its gradient w.r.t. the candidates.
+ * Replaces: the derivatives ForwardDiff pushes through nonstationary_gp.jl:153-196 inside OptimizationAM
+ * (src/acquisition_maximizers/optimization.jl:36,89-118).  The candidate enters the Gibbs kernel directly and through the
+ * latent l(x*), a(x*), whose Jacobians arrive evaluated like their values (the latent models are the caller's):
+ *   dlam_Xs d×d×M, dlam_Xs[l + d*(m + d*j)] = d l_l / d x_m at candidate j, or NULL (constant lengthscales);
+ *   damp_Xs d×M,   damp_Xs[m + d*j]         = d a / d x_m,                  or NULL (constant amplitude);
+ *   mean_Xs M / mean_grad d×M prior mean and its gradient at the candidates, or NULL;
+ *   mu, var (clipped like boss_ngp_predict), dmu, dvar d×M column-major (gradient of the UNclipped variance).
+ * Dims flagged discrete get a zero explicit part; the caller passes zero Jacobian columns for them.  x_dim <= 16. */
+int boss_ngp_predict_grad(boss_gp_t* gp, int M, const double* Xs, const double* lam_Xs, const double* amp_Xs,
+                          const double* dlam_Xs, const double* damp_Xs, const double* mean_Xs, const double* mean_grad,
+                          double* mu, double* var, double* dmu, double* dvar, long* bad_index);
 
 /* ---- batched log-likelihood -----------------------------------------------------------
  * Replaces: the `loglike.(samples)` loop of SamplingMAP (src/model_fitters/sampling.jl:59-78) and the
@@ -300,6 +313,13 @@ int boss_acq_ei_moments(int device, int P, int S, int M, const double* mu, const
                         const double* fit_coefs, const double* y_max, int has_best, double best,
                         const unsigned char* valid_mask, double* acq_out, long* argmax_out,
                         double* max_out);
+
+/* The chain rule of boss_acq_ei_grad (construct_ei, expected_improvement.jl:68-101,113-114) from moments and moment gradients the
+ * caller already holds — boss_ngp_predict_grad per output of a nonstationary model, or outputs fitted on other ranks:
+ *   mu / var P×M (row p at p*M; var clipped), dmu / dvar P blocks of d×M column-major;  the other arguments as boss_acq_ei_grad. */
+int boss_acq_ei_grad_moments(int device, int P, int M, int d, const double* mu, const double* var, const double* dmu,
+                             const double* dvar, const double* fit_coefs, const double* y_max, int has_best, double best,
+                             const unsigned char* valid_mask, double* acq_out, double* dacq_out);
 
 /* Acquisition value AND its gradient w.r.t. the candidates, for one hyper-parameter
  * sample (MAP).  Replaces: differentiating construct_acquisition(::ExpectedImprovement)

@@ -877,3 +877,45 @@ def nonstationary_mean_and_var(post: NonstationaryPosterior, Xs, lam_Xs, amp_Xs,
     V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
     var = np.asarray(amp_Xs, np.float64) ** 2 - np.sum(V * V, axis=0) + PREDICT_JITTER
     return mu, (clip_var(var) if clip else var)
+
+
+def nonstationary_mean_and_var_grad(post: NonstationaryPosterior, Xs, lam_Xs, amp_Xs, dlam_Xs=None, damp_Xs=None, mean_s=None,
+                                    mean_grad_s=None):
+    """What ForwardDiff yields when OptimizationAM (src/acquisition_maximizers/optimization.jl:36,89-118) differentiates through a
+    NonstationaryGP posterior (src/models/nonstationary_gp/nonstationary_gp.jl:153-196): the candidate enters the Gibbs kernel
+    directly AND through the latent λ(x*), α(x*); their Jacobians arrive evaluated, as the values do —
+        dlam_Xs[l, m, j] = ∂λ_l/∂x_m at candidate j (None: constant λ),  damp_Xs[m, j] = ∂α/∂x_m (None: constant α).
+    With q_l = λ_il² + λ*_l², Δ_l = x_il − x*_l:
+        ∂ln k_i/∂x*_m (explicit) = 2 Δ_m / q_m ,   ∂ln k_i/∂λ*_l = ½ (1/λ*_l − 2 λ*_l/q_l) + 2 λ*_l Δ_l²/q_l² ,   ∂ln k_i/∂α* = 2/(α_i + α*)
+        ∇μ = ∇m + Σ_i a_i ∇k_i ,   ∇σ² = 2 α* ∇α* − 2 Σ_i w_i ∇k_i ,  w = K⁻¹k*.
+    The reference holds no test for this model (PARITY UNPINNED; pinned here on finite differences, tests/test_oracle_crosscheck.py).
+    Discrete dimensions: the caller passes zero Jacobian columns and gets a zero explicit part.
+    Returns (mu[M], var[M] unclipped, dmu[d, M], dvar[d, M])."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    if Xs.ndim == 1:
+        Xs = Xs[:, None]
+    d, M = Xs.shape
+    lam_Xs = np.asarray(lam_Xs, np.float64).reshape(d, M)
+    amp_Xs = np.asarray(amp_Xs, np.float64).reshape(M)
+    Xr, Xsr = discrete_round(post.X, post.discrete), discrete_round(Xs, post.discrete)
+    Ks = gibbs_kernel_matrix(Xr, post.lam_X, post.amp_X, Xsr, lam_Xs, amp_Xs)
+    mu = _mean_vec(mean_s, Xs) + Ks.T @ post.a
+    V = sla.solve_triangular(post.L, Ks, lower=True, check_finite=False)
+    W = sla.solve_triangular(post.L, V, lower=True, trans="T", check_finite=False)
+    var = amp_Xs ** 2 - np.sum(V * V, axis=0) + PREDICT_JITTER
+    Dl = np.zeros((d, d, M)) if dlam_Xs is None else np.asarray(dlam_Xs, np.float64).reshape(d, d, M)
+    Da = np.zeros((d, M)) if damp_Xs is None else np.asarray(damp_Xs, np.float64).reshape(d, M)
+    disc = np.zeros(d, bool) if post.discrete is None else np.asarray(post.discrete, bool)
+    dmu = np.zeros((d, M)) if mean_grad_s is None else np.array(mean_grad_s, dtype=np.float64).reshape(d, M)
+    dvar = np.zeros((d, M))
+    for j in range(M):
+        q = post.lam_X ** 2 + lam_Xs[:, j:j + 1] ** 2                      # d × N
+        dlt = Xr - Xsr[:, j:j + 1]
+        e = np.where(disc[:, None], 0.0, 2.0 * dlt / q)                    # explicit part
+        c = 0.5 * (1.0 / lam_Xs[:, j:j + 1] - 2.0 * lam_Xs[:, j:j + 1] / q) + 2.0 * lam_Xs[:, j:j + 1] * dlt ** 2 / q ** 2
+        sa = 2.0 / (post.amp_X + amp_Xs[j])                                # N
+        G = e + Dl[:, :, j].T @ c + np.outer(Da[:, j], sa)                 # d × N: ∇_{x*} ln k_i
+        gk = G * Ks[:, j][None, :]
+        dmu[:, j] += gk @ post.a
+        dvar[:, j] = 2.0 * amp_Xs[j] * Da[:, j] - 2.0 * (gk @ W[:, j])
+    return mu, var, dmu, dvar

@@ -1836,6 +1836,55 @@ def test_nonstationary_gp_parity(api, O, d, N, M):
     g.close()
 
 
+@pytest.mark.parametrize("d,N,M", [(1, 20, 5), (3, 300, 70), (8, 1100, 40), (16, 150, 33)])
+def test_nonstationary_gp_candidate_gradients(api, O, d, N, M):
+    """SURVEY §8f3 over §8f4: ∇μ, ∇σ² of a nonstationary posterior — the candidate enters the Gibbs kernel directly and through
+    the latent λ(x*), α(x*) (nonstationary_gp.jl:61-107,153-196 under the ForwardDiff of optimization.jl:36) — and the EI chain rule
+    from those moments.  Against the oracle's analytic gradients (finite-difference checked in tests/test_oracle_crosscheck.py)."""
+    X, y, Xs = make(d, N, M, seed=14)
+    Xs = np.asfortranarray(0.05 + 0.9 * Xs)
+    w = np.linspace(0.5, 1.5, d)
+    f_lam = lambda x: 0.3 + 0.4 * np.asarray(x) ** 2 + 0.05 * np.arange(1, d + 1) + 0.1 * np.sin(w @ np.asarray(x))    # noqa: E731
+    J_lam = lambda x: np.diag(0.8 * np.asarray(x)) + 0.1 * np.cos(w @ np.asarray(x)) * np.tile(w, (d, 1))               # noqa: E731
+    f_amp = lambda x: 1.0 + 0.4 * np.sin(3 * x[0]) + 0.1 * x[-1]                                                        # noqa: E731
+    def J_amp(x):
+        g = np.zeros(d)
+        g[0] += 1.2 * np.cos(3 * x[0])
+        g[-1] += 0.1
+        return g
+    f_noise = lambda x: 0.05 + 0.02 * x[0]                                                                               # noqa: E731
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                                                  # noqa: E731
+    lamX, ampX, noiX = ev(f_lam, X).T, ev(f_amp, X), ev(f_noise, X)
+    lamS, ampS = ev(f_lam, Xs).T, ev(f_amp, Xs)
+    Dl = np.stack([J_lam(Xs[:, j]) for j in range(M)], axis=2)
+    Da = np.stack([J_amp(Xs[:, j]) for j in range(M)], axis=1)
+    mX, mS = 0.3 * X[0], 0.3 * Xs[0]
+    mg = np.zeros((d, M))
+    mg[0] = 0.3
+    post = O.nonstationary_fit(X, y, lamX, ampX, noiX, mean=mX)
+    mu_o, var_o, dmu_o, dvar_o = O.nonstationary_mean_and_var_grad(post, Xs, lamS, ampS, Dl, Da, mS, mg)
+    K = post.L @ post.L.T
+    tol = max(1e-9, np.linalg.cond(K) * N * 2.0 ** -53 * 8)
+    g = api.GibbsGP(X, y)
+    g.update(lamX, ampX, noiX, mX)
+    mu, var, dmu, dvar = g.predict_grad(Xs, lamS, ampS, Dl, Da, mS, mg)
+    assert np.abs(mu - mu_o).max() <= tol * (1 + np.abs(mu_o).max())
+    assert np.abs(var - np.maximum(var_o, 0.0)).max() <= tol * ampS.max() ** 2
+    assert np.abs(dmu - dmu_o).max() <= tol * (1 + np.abs(dmu_o).max()) * 10, np.abs(dmu - dmu_o).max()
+    assert np.abs(dvar - dvar_o).max() <= tol * (1 + np.abs(dvar_o).max()) * 10, np.abs(dvar - dvar_o).max()
+    # constant latent models: no Jacobians
+    mu_c, var_c, dmu_c, dvar_c = O.nonstationary_mean_and_var_grad(post, Xs, lamS, ampS)
+    _, _, dmu2, dvar2 = g.predict_grad(Xs, lamS, ampS)
+    assert np.abs(dmu2 - dmu_c).max() <= tol * (1 + np.abs(dmu_c).max()) * 10 and np.abs(dvar2 - dvar_c).max() <= tol * (1 + np.abs(dvar_c).max()) * 10
+    # the acquisition's chain rule from the moments (boss_acq_ei_grad_moments)
+    best = float(y.max()) - 0.2
+    vo = np.maximum(var_o, 0.0)
+    acq_o, dacq_o = O.expected_improvement_lin_grad([1.0], mu_o[None], vo[None], dmu_o[None], np.where(vo > 0, dvar_o, 0.0)[None], best)
+    acq, dacq = api.acq_ei_grad_moments(mu[None], var[None], dmu[None], dvar[None], [1.0], None, best)
+    assert np.abs(acq - acq_o).max() <= tol * 10 and np.abs(dacq - dacq_o).max() <= tol * (1 + np.abs(dacq_o).max()) * 100
+    g.close()
+
+
 def test_nonstationary_gp_constant_parameters_equal_the_sqexp_model(api, O):
     """With constant latent parameters the Gibbs kernel is the ARD squared-exponential kernel: the nonstationary
     entry points must reproduce the plain ones on the device as well (the plain model adds 1e-8 to its parameters)."""
@@ -1889,12 +1938,22 @@ def test_nonstationary_gp_discrete_errors_and_host_mirror(api, O):
     assert np.allclose(acq, want, rtol=0, atol=1e-12) and am == int(np.argmax(want))
     g = posts[0].gp
     for call in (lambda: api.GP.update(g, [1.0, 1.0], 1.0, 0.1), lambda: api.GP.predict(g, Xs), lambda: g.append(X[:, :1], [0.0]),
-                 lambda: g.predict_grad(Xs), lambda: g.predict_cov(Xs), lambda: g.loglike_grad(),
+                 lambda: api.GP.predict_grad(g, Xs), lambda: g.predict_cov(Xs), lambda: g.loglike_grad(),
                  lambda: api.acq_ei([[g]], api.Candidates(Xs), [1.0], None, 0.0, None),
                  lambda: g.update(np.zeros((d, N)), np.ones(N), np.ones(N)),             # λ = 0
                  lambda: g.update(np.ones((d, N)), -np.ones(N), np.ones(N))):
         with pytest.raises(api.BossError):
             call()
+    # the mirror's gradient of mean_and_var (latent Jacobians by central differences of the host closures) against its own differences
+    Xg = np.asfortranarray(Xs[:, :5])
+    if posts[0].discrete is None:
+        mu_g, var_g, dmu_g, dvar_g = posts[0].mean_and_var_grad(Xg)
+        for m in range(d):
+            Zp, Zm = Xg.copy(), Xg.copy()
+            Zp[m] += 1e-5
+            Zm[m] -= 1e-5
+            (mp, vp), (mm, vm) = posts[0].mean_and_var(Zp), posts[0].mean_and_var(Zm)
+            assert np.abs((mp - mm) / 2e-5 - dmu_g[m]).max() <= 1e-5 * (1 + np.abs(dmu_g).max())
     # identical points without noise -> PosDefException; data_loglike maps it to -Inf (safe_data_loglike)
     Xd = np.tile(X[:, :1], (1, 4))
     gd = api.GibbsGP(Xd, np.arange(4.0))

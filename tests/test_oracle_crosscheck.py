@@ -331,3 +331,38 @@ def test_gradient_gp_candidate_gradients_match_finite_differences():
             (mp, vp), (mm, vm) = f(Zp), f(Zm)
             assert np.abs((mp - mm) / (2 * e) - dmu[m]).max() <= 1e-6 * (1 + np.abs(dmu[m]).max())
             assert np.abs((vp - vm) / (2 * e) - dvar[m]).max() <= 1e-6 * (1 + np.abs(dvar[m]).max())
+
+
+def test_nonstationary_candidate_gradients_match_finite_differences():
+    """oracle.nonstationary_mean_and_var_grad (Gibbs kernel with the candidate entering through λ(x*), α(x*) as well,
+    /root/reference/src/models/nonstationary_gp/nonstationary_gp.jl:61-107,153-196) against central differences."""
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(1)
+    d, N, M = 3, 25, 6
+    X = rng.uniform(0, 1, (d, N))
+    y = np.sin(3 * X).sum(0)
+    A = rng.uniform(0.2, 0.5, (d, d))
+    b0 = np.array([0.4, 0.5, 0.6])
+    lamf = lambda Z: b0[:, None] + 0.2 * np.sin(A @ Z)                       # noqa: E731
+    dlamf = lambda z: 0.2 * np.cos(A @ z)[:, None] * A                       # noqa: E731
+    ca = np.array([0.3, -0.2, 0.1])
+    ampf = lambda Z: 1.0 + 0.3 * np.tanh(ca @ Z)                             # noqa: E731
+    dampf = lambda z: 0.3 * (1 - np.tanh(ca @ z) ** 2) * ca                  # noqa: E731
+    post = O.nonstationary_fit(X, y, lamf(X), ampf(X), np.full(N, 0.05), mean=0.1 * X[0])
+    Xs = rng.uniform(0, 1, (d, M))
+    Dl = np.stack([dlamf(Xs[:, j]) for j in range(M)], axis=2)
+    Da = np.stack([dampf(Xs[:, j]) for j in range(M)], axis=1)
+    mg = np.zeros((d, M))
+    mg[0] = 0.1
+    mu, var, dmu, dvar = O.nonstationary_mean_and_var_grad(post, Xs, lamf(Xs), ampf(Xs), Dl, Da, 0.1 * Xs[0], mg)
+    f = lambda Z: O.nonstationary_mean_and_var(post, Z, lamf(Z), ampf(Z), 0.1 * Z[0], clip=False)   # noqa: E731
+    mu0, var0 = f(Xs)
+    assert np.allclose(mu, mu0, rtol=0, atol=1e-12) and np.allclose(var, var0, rtol=0, atol=1e-12)
+    e = 1e-6
+    for m in range(d):
+        Zp, Zm = Xs.copy(), Xs.copy()
+        Zp[m] += e
+        Zm[m] -= e
+        (mp, vp), (mm, vm) = f(Zp), f(Zm)
+        assert np.abs((mp - mm) / (2 * e) - dmu[m]).max() <= 1e-6 * (1 + np.abs(dmu[m]).max())
+        assert np.abs((vp - vm) / (2 * e) - dvar[m]).max() <= 1e-6 * (1 + np.abs(dvar[m]).max())
