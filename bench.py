@@ -470,6 +470,23 @@ def main():
         return t1 - t0, t2 - t1
 
     s_elapsed, s_upd, s_acq = timed(step_strong, args.steps, args.warmup)
+    # the same step as ONE call per rank where the shard is small enough for the substitution to ride along the replicated update
+    # (boss_gp_update_acq, csrc/rider.hpp): at G = 8 every rank holds 1024 candidates
+    fused_strong = None
+    if hi - lo <= 4096:
+        rode = []
+
+        def step_fused(i):
+            t0 = time.perf_counter()
+            r = gps.update_acq(lam, 1.0, 0.05 + 1e-4 * (i % 7), cand_s, best=best_s)
+            am, mx = r["argmax"], r["max"]
+            if world > 1:
+                mx, am = dist_util.argmax_exchange(mx, am + lo)
+            rode.append(r["fused"])
+            return time.perf_counter() - t0, 0.0
+        f_elapsed, _, _ = timed(step_fused, args.steps, args.warmup)
+        fused_strong = {"ms_per_step": f_elapsed / args.steps * 1e3, "steps_per_sec": args.steps / f_elapsed,
+                        "rode_along": bool(all(rode)), "speedup_over_two_calls": s_elapsed / f_elapsed}
     strong = {
         "scaling": "strong", "metric": "acq_evals_per_sec, 8192 candidates of ONE N=4096 posterior sharded M/G (+ replicated update)",
         "value": args.steps * M_CAND / s_acq, "unit": "evals/s", "n_gpus": world, "M_per_gpu": hi - lo,
@@ -479,6 +496,7 @@ def main():
                            "256-row substitution steps spread over the chip (few-candidates path, first call on a factorisation)",
         "argmax": [int(winner[0][0]), float(winner[0][1])],
         "exchange": "none" if world == 1 else f"16-byte all-gather over {backend}",
+        "one_call_per_step": fused_strong,
     }
 
     # ---- per-kernel HIP-event timing of the dominant kernels (separate pass, events on the library's stream)

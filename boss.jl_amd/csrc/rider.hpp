@@ -137,7 +137,7 @@ struct RiderStep {
     const unsigned long long* sig;                           // the context's signal block
     int* info;
     unsigned long long want;                                 // value the watched words must reach before block k is solved
-    int ld, Np, N, Mp, d, kern, k, nblk, nstrips, nslots, cb, nchunks, xcd_map;
+    int ld, Np, N, Mp, d, kern, k, nblk, nstrips, nslots, cb, nchunks;
 #ifdef BOSS_EXPERIMENTS
     int exp;                                                 // timing experiments: bit 0 skips the E products, bit 1 the fold products, bit 2 sleeps between E products
 #endif
@@ -173,19 +173,10 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
         // ---------------- E_k: block row k+1, one (strip, chunk) item per workgroup; chunk ch takes the blocks
         // [ch·cb, min((ch+1)·cb, k-1)), its first half on waves 0..3, the second on waves 4..7 (summed through LDS in that order) —
         // strips fastest: the workgroups of a chunk share their slice of L
-        // Workgroup b runs on XCD b mod 8 (workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own): where the
-        // chunk count divides eight, every XCD serves ONE chunk — its slice of L[k+1, ·] comes over the fabric once instead of eight times
-        // (at k = 30, 1024 candidates: 4 instead of 31 MB per step, beside the 31 MB of V) — the fabric the chain's hand-offs travel on.
+        // (measured and removed: chunk c on XCD c, so that every slice of L[k+1, ·] crosses the fabric once instead of eight times —
+        // 1.33–1.35 against 1.25–1.29 ms per call at 1024 candidates: the last chunk is shorter than the others and its XCD idles)
         const int item = (int)blockIdx.x - nstrips;
-        int strip, ch;
-        if (p.xcd_map && (8 % p.nchunks) == 0 && ((nstrips * p.nchunks) & 7) == 0) {
-            const int x = (int)blockIdx.x & 7, t = item >> 3, per = 8 / p.nchunks;
-            ch = x % p.nchunks;
-            strip = t * per + x / p.nchunks;
-        } else {
-            strip = item % nstrips;
-            ch = item / nstrips;
-        }
+        const int strip = item % nstrips, ch = item / nstrips;
         const int krow = k + 1, j0 = ch * p.cb, j1 = min(j0 + p.cb, k - 1);
         const int jm = j1 - j0 >= 2 ? j0 + (j1 - j0 + 1) / 2 : j1;   // group 0: [j0, jm), group 1: [jm, j1)
         const int ja = grp == 0 ? j0 : jm, jz = grp == 0 ? jm : j1;
