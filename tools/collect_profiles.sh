@@ -8,8 +8,8 @@
 # usage: bash tools/collect_profiles.sh r03_v1
 set -e
 tag=${1:-r03}
-out=gpurun_out/prof_$tag
-mkdir -p $out profiles
+out=/tmp/prof_$tag          # raw profiler output stays on the box (hundreds of MB); only the summaries travel back
+mkdir -p $out profiles gpurun_out
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/bench_stats.json 2> $out/stats.err
 cp $(find $out/stats -name "s_kernel_stats.csv" | head -1) profiles/${tag}_bench_kernel_stats.csv
@@ -20,6 +20,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MO
 python3 tools/pmc_summary.py $(find $out/pmc_f -name "f_counter_collection.csv" | head -1) $(find $out/pmc_w -name "w_counter_collection.csv" | head -1) profiles/${tag}_pmc_summary.json $(find $out/pmc_m -name "m_counter_collection.csv" | head -1)
 python3 bench.py --steps 50 --warmup 5 > profiles/${tag}_bench.json 2> $out/bench.err
 if [ -f tools/libbosship_t3.so ]; then python3 tools/chain_trace3.py 4096 > profiles/${tag}_chain_timeline.log 2> $out/trace.err || true; fi
-cp profiles/${tag}_pmc_summary.json profiles/${tag}_bench_kernel_stats.csv profiles/${tag}_bench.json gpurun_out/
-[ -f profiles/${tag}_chain_timeline.log ] && cp profiles/${tag}_chain_timeline.log gpurun_out/
 echo "profiles written for $tag"
+if [ -f tools/libbosship_t3.so ]; then python3 tools/rider_timeline.py > profiles/${tag}_rider_timeline.log 2> $out/rider_trace.err || true; fi
+python3 tools/rider_time.py > profiles/${tag}_rider_time.log 2> $out/rider_time.err || true
+python3 tools/stall_hunt.py > profiles/${tag}_update_latency_2000.log 2> $out/stall.err || true
+# 300 back-to-back updates under the kernel trace: chain-kernel durations and main-stream gaps inside every update
+REP=300 rocprofv3 --kernel-trace --output-format csv -d $out/upd300 -o u -- python3 tools/stall_hunt.py > $out/upd300.log 2> $out/upd300.err || true
+python3 tools/trace_gaps.py $(find $out/upd300 -name "u_kernel_trace.csv" | head -1) > profiles/${tag}_update_trace_gaps.log 2>> $out/upd300.err || true
+mkdir -p gpurun_out/profiles_$tag && cp profiles/${tag}_* gpurun_out/profiles_$tag/ && cp $out/*.err gpurun_out/profiles_$tag/ 2>/dev/null || true
