@@ -14,6 +14,7 @@ KERN = ["matern32", "matern52", "sqexp"]
 NS = [1, 2, 17, 127, 128, 129, 255, 256, 257, 300, 511, 513, 700, 1023, 1024, 1025, 1100, 1536, 2047, 2300]
 MS = [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 100, 224, 500, 1100, 1537]
 worst = 0.0
+nfused = 0
 t_start = time.time()
 for case in range(first, ncases):
     rng = np.random.default_rng(seed0 * 1000 + case)
@@ -45,7 +46,7 @@ for case in range(first, ncases):
     track = tcand = tXs = None
     for step in range(int(rng.integers(4, 10))):
         op = rng.choice(["predict", "predict", "predict", "grad", "cov", "append", "append", "update", "llgrad", "track", "acq", "acqgrad",
-                         "batch"])
+                         "batch", "update_acq", "update_acq"])
         ops.append(op)
         try:
             if op == "predict":
@@ -88,6 +89,28 @@ for case in range(first, ncases):
                 post = O.gp_fit(X, y, kern, lam, amp, sig, mean=mfun(X), discrete=disc)
                 e = abs(lp - post.logpdf) / (1 + abs(post.logpdf))
                 if track is not None:                      # a track belongs to one set of hyper-parameters
+                    track.close()
+                    track = None
+            elif op == "update_acq":
+                # boss_gp_update_acq: new hyper-parameters and the first acquisition in one call (rides along the
+                # factorisation when the handle and candidate count allow it, two enqueued steps otherwise)
+                lam = rng.uniform(0.3, 0.9, d) * scale
+                amp, sig = float(rng.uniform(0.7, 1.5)), float(rng.uniform(0.03, 0.1))
+                M = int(rng.choice([1, 5, 63, 64, 129, 500, 1024, 1100, 2048]))
+                Xs = np.asfortranarray(rng.uniform(-0.05 * scale, 1.05 * scale, (d, M)))
+                mask = O.in_bounds(Xs, np.zeros(d), np.full(d, scale)) if rng.random() < 0.5 else None
+                ymax = None if rng.random() < 0.5 else float(y.max()) + 0.5
+                best = float(np.median(y)) if rng.random() < 0.8 else None
+                r = g.update_acq(lam, amp, sig, api.Candidates(Xs), 1.0, ymax, best, mfun(X), mfun(Xs), mask, want_acq=True, want_moments=True)
+                post = O.gp_fit(X, y, kern, lam, amp, sig, mean=mfun(X), discrete=disc)
+                mu_o, var_o = O.gp_mean_and_var(post, Xs, mfun(Xs), clip=False)
+                want = O.ei_acquisition([post], Xs, [1.0], None if ymax is None else [ymax], best, valid_mask=mask,
+                                        means_s=None if not use_mean else [mfun(Xs)])
+                e = max(abs(r["logpdf"] - post.logpdf) / (1 + abs(post.logpdf)), np.abs(r["mu"] - mu_o).max() / (1 + np.abs(mu_o).max()),
+                        np.abs(r["var"] - var_o).max() / amp ** 2, np.abs(r["acq"] - want).max())
+                assert r["argmax"] == int(np.argmax(r["acq"])) and r["max"] == r["acq"].max(), ("update_acq argmax", case)
+                nfused = nfused + int(r["fused"])
+                if track is not None:
                     track.close()
                     track = None
             elif op == "batch":
@@ -186,4 +209,4 @@ for case in range(first, ncases):
     g.close()
     if case % 5 == 4:
         print(f"  {case + 1} cases ok, worst error/tolerance so far {worst:.2e}, {time.time() - t_start:.0f} s", flush=True)
-print(f"fuzz: {ncases} cases passed, worst error/tolerance {worst:.2e}")
+print(f"fuzz: {ncases} cases passed, worst error/tolerance {worst:.2e}, {nfused} fused update_acq calls")
