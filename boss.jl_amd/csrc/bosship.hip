@@ -302,6 +302,7 @@ static int ctx_init(Ctx* c) {
     HIPCHK(hipFuncSetAttribute((const void*)small_predict_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)small_predict_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPG_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_syrk_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)rider_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                PredictLds<PredG32>::BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)predict_kernel_set<PredG32>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -30,16 +30,25 @@
 namespace boss {
 
 constexpr int RIDER_MAX_CH = 8;                              // K-chunks per block row (partial-sum slots)
-constexpr int RIDER_LDS_BYTES = 8 * 1024;                    // occupancy limiter (unused dynamic LDS on top of 59 KB static): never beside a strips workgroup (100 KB of 160)
-#ifndef BOSS_RIDER_D
-#define BOSS_RIDER_D 16                                      // ring depth: the rider's operands are cold misses (written by other CUs moments before) and
-#endif                                                       // few waves share a CU — what counts is how few memory round trips a K = 128 product takes (32 substeps / D)
-typedef GemmDirect<1, 4, 2, 2, BOSS_RIDER_D> RiderG;         // 32 candidates × 128 rows per group of four waves, operands streamed from L2
-constexpr int RIDER_THREADS = 512;                           // two such groups per workgroup
+constexpr int RIDER_LDS_BYTES = 24 * 1024;                   // occupancy limiter (unused dynamic LDS on top of 59 KB static): one workgroup per CU, never beside a strips workgroup
+                                                             // (90 KB of 160; at 8 KB = two per CU: 1.25 against 1.21 ms per call at 1024 candidates, 1.57 / 1.52 at 2048)
+#ifndef BOSS_RIDER_TN
+#define BOSS_RIDER_TN 2                                      // 16-row tiles per wave along the block row.  2: 32 candidates × 32 rows per wave, two groups of four waves
+#endif                                                       // split K; 4: 32 × 64 per wave (three operand loads per eight MFMAs instead of two per four), four groups of
+#ifndef BOSS_RIDER_D                                         // two, ring depth 8 — measured SLOWER (1.38 against 1.21 ms per call at 1024 candidates, 1.64 / 1.52 at 2048:
+#define BOSS_RIDER_D (BOSS_RIDER_TN == 2 ? 16 : 8)           // the step is bound by latencies and launch boundaries, not by operand bytes; tools/rider_probe.py)
+#endif                                                       // ring depth: K ranges are handed out in units of 4·D columns
+typedef GemmDirect<1, 8 / BOSS_RIDER_TN, 2, BOSS_RIDER_TN, BOSS_RIDER_D> RiderG;   // 32 candidates × 128 rows per group of waves, operands streamed from L2
+constexpr int RIDER_THREADS = 512;
+constexpr int RIDER_GW = RiderG::WC;                         // waves per group
+constexpr int RIDER_NG = 8 / RIDER_GW;                       // groups per workgroup: they split K
+constexpr int RIDER_KU = 4 * BOSS_RIDER_D;                   // K unit of a group's share (the exact ring needs whole ring passes)
+static_assert((BLK / RIDER_NG) % RIDER_KU == 0, "a K = 128 product is split evenly over the groups");
+static_assert(BLK % RIDER_KU == 0 && RIDER_MAX_CH % RIDER_NG == 0, "K units, slots per group");
 
-// one 32×128 strip product on this wave's group of four (grp = 1: waves 4..7): GemmDirect derives a row offset of 32 from the wave
-// index of the second group, which the A pointer takes back.  A32: the strip's 32 candidates (lda 32).
-__device__ __forceinline__ void rider_gemm(const double* __restrict__ A32, const double* __restrict__ B, int ldb, int K, v4d (&acc)[2][2], int grp) {
+// one 32×128 strip product on this wave's group (grp = wave / RIDER_GW): GemmDirect derives a row offset of 32·grp from the wave
+// index, which the A pointer takes back.  A32: the strip's 32 candidates (lda 32).  K: a multiple of RIDER_KU (or 0).
+__device__ __forceinline__ void rider_gemm(const double* __restrict__ A32, const double* __restrict__ B, int ldb, int K, v4d (&acc)[2][RiderG::TN], int grp) {
     RiderG::template run<-1, true>(A32 - 32 * grp, 32, B, ldb, K, acc);
 }
 
@@ -77,39 +86,42 @@ __global__ __launch_bounds__(64) void rider_gate_kernel(const unsigned long long
 __device__ __forceinline__ size_t rider_part_off(int slot, int nstrips, int strip32) { return ((size_t)slot * nstrips + strip32) * (BLK * 32); }
 
 // The K* tile (32 candidates of `strip` × block row krow) in RiderG's accumulator layout: lane (r16, q) of wave wc holds candidates
-// 2 r16, 2 r16 + 1 × rows wc·32 + 2 (q + 4 i) + n.  The coordinates are fetched eight dimensions at a time (one memory round trip
-// per eight, not one per dimension: a workgroup of this kernel is a handful of waves on an otherwise idle CU).
-__device__ __forceinline__ void rider_kstar_tile(v4d (&acc)[2][2], const double* __restrict__ Xsc, const double* __restrict__ Csc, int d,
+// 2 r16, 2 r16 + 1 × rows col_of(wc, n, i, lane).  The coordinates are fetched several dimensions at a time (one memory round trip
+// per four or eight, not one per dimension: a workgroup of this kernel is a handful of waves on an otherwise idle CU).
+__device__ __forceinline__ void rider_kstar_tile(v4d (&acc)[2][RiderG::TN], const double* __restrict__ Xsc, const double* __restrict__ Csc, int d,
                                                  int Np, int N, int Mp, int kern, double amp2, int krow, int strip, int wc, int lane) {
+    constexpr int TN = RiderG::TN, PN = RiderG::PN, DU = 8 / PN;   // dimensions per memory round trip
     const int r16 = lane & 15, q = lane >> 4;
-    double r2[2][2][4];
+    double r2[2][TN][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int i = 0; i < 4; ++i) r2[m][n][i] = 0.0;
     const double* cp = Csc + (size_t)strip * 32 + 2 * r16;
-    const double* xp = Xsc + (size_t)krow * BLK + wc * 32 + 2 * q;
-    for (int d0 = 0; d0 < d; d0 += 8) {
-        v2d cv[8], xv[8][4];
+    const double* xp = Xsc + (size_t)krow * BLK + wc * (TN * 16) + 2 * q;
+    for (int d0 = 0; d0 < d; d0 += DU) {
+        v2d cv[DU], xv[DU][PN][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DU; ++u) {
             const int dd = min(d0 + u, d - 1);
             cv[u] = *reinterpret_cast<const v2d*>(cp + (size_t)dd * Mp);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xv[u][i] = *reinterpret_cast<const v2d*>(xp + (size_t)dd * Np + 8 * i);
+            for (int pn = 0; pn < PN; ++pn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[u][pn][i] = *reinterpret_cast<const v2d*>(xp + (size_t)dd * Np + 32 * pn + 8 * i);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DU; ++u) {
             if (d0 + u < d) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) {
-                            const double df = xv[u][i][n] - cv[u][m];
+                        for (int n = 0; n < TN; ++n) {
+                            const double df = xv[u][n >> 1][i][n & 1] - cv[u][m];
                             r2[m][n][i] = __builtin_fma(df, df, r2[m][n][i]);
                         }
             }
@@ -118,7 +130,7 @@ __device__ __forceinline__ void rider_kstar_tile(v4d (&acc)[2][2], const double*
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = krow * BLK + RiderG::col_of(wc, n, i, lane);
@@ -138,6 +150,7 @@ struct RiderStep {
     int* info;
     unsigned long long want;                                 // value the watched words must reach before block k is solved
     int ld, Np, N, Mp, d, kern, k, nblk, nstrips, nslots, cb, nchunks;
+    int efirst;                                              // E workgroups first in the grid (one per CU before the S workgroups double up)
 #ifdef BOSS_EXPERIMENTS
     int exp;                                                 // timing experiments: bit 0 skips the E products, bit 1 the fold products, bit 2 sleeps between E products
 #endif
@@ -165,90 +178,110 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
     __shared__ double red[2][2][16], zred[16][32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wc = wave & 3;                // group of four waves, column quarter inside the group's 32×128 tile
+    const int grp = wave / RIDER_GW, wc = wave % RIDER_GW;   // group of waves (one 32×128 tile, a share of K), column part inside the tile
+    constexpr int TN = G::TN, NG = RIDER_NG;
     const int k = p.k, ld = p.ld, Np = p.Np, nstrips = p.nstrips;
-    v4d acc[2][2];
+    v4d acc[2][TN];
+    auto rl_at = [&](int n, int i) { return reinterpret_cast<v2d*>(Rl + G::col_of(wc, n, i, lane) * 32 + G::row_of(0, 0, lane)); };
+    // the groups' tiles summed through Rl in group order 1, 2, …, (group 0 holds its own until the end: the caller adds it last)
+    auto fold_groups = [&]() {
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+            if (grp == g) {
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v2d o = v2d{acc[0][n][i], acc[1][n][i]};
+                        if (g > 1) o += *rl_at(n, i);
+                        *rl_at(n, i) = o;
+                    }
+            }
+            __syncthreads();
+        }
+    };
     RTRACE_MIN(k, 0);
-    if ((int)blockIdx.x >= nstrips) {
+    const int nE = (int)gridDim.x - nstrips;
+    if (p.efirst ? (int)blockIdx.x < nE : (int)blockIdx.x >= nstrips) {
         // ---------------- E_k: block row k+1, one (strip, chunk) item per workgroup; chunk ch takes the blocks
-        // [ch·cb, min((ch+1)·cb, k-1)), its first half on waves 0..3, the second on waves 4..7 (summed through LDS in that order) —
+        // [ch·cb, min((ch+1)·cb, k-1)), its columns dealt to the groups in units of RIDER_KU (summed through LDS in group order) —
         // strips fastest: the workgroups of a chunk share their slice of L
         // (measured and removed: chunk c on XCD c, so that every slice of L[k+1, ·] crosses the fabric once instead of eight times —
         // 1.33–1.35 against 1.25–1.29 ms per call at 1024 candidates: the last chunk is shorter than the others and its XCD idles)
-        const int item = (int)blockIdx.x - nstrips;
+        const int item = p.efirst ? (int)blockIdx.x : (int)blockIdx.x - nstrips;
         const int strip = item % nstrips, ch = item / nstrips;
         const int krow = k + 1, j0 = ch * p.cb, j1 = min(j0 + p.cb, k - 1);
-        const int jm = j1 - j0 >= 2 ? j0 + (j1 - j0 + 1) / 2 : j1;   // group 0: [j0, jm), group 1: [jm, j1)
-        const int ja = grp == 0 ? j0 : jm, jz = grp == 0 ? jm : j1;
+        const int units = max(j1 - j0, 0) * (BLK / RIDER_KU);
+        const int ua = units * grp / NG, uz = units * (grp + 1) / NG;
         if (ch == 0 && grp == 0) rider_kstar_tile(acc, p.Xsc, p.Csc, p.d, Np, p.N, p.Mp, p.kern, p.amp2, krow, strip, wc, lane);
         else {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+                for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
         }
 #ifdef BOSS_EXPERIMENTS
         if (!(p.exp & 1))
 #endif
-        if (jz > ja)
-            rider_gemm(p.V + (size_t)strip * Np * 32 + (size_t)ja * BLK * 32, p.A + (size_t)krow * BLK + (size_t)ja * BLK * ld, ld, (jz - ja) * BLK, acc, grp);
-        if (j1 > jm) {                                       // (uniform over the workgroup)
-            if (grp == 1) {
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<v2d*>(Rl + G::col_of(wc, n, i, lane) * 32 + G::row_of(0, 0, lane)) = v2d{acc[0][n][i], acc[1][n][i]};
-            }
-            __syncthreads();
+        if (uz > ua) {
+            const size_t c0 = (size_t)j0 * BLK + (size_t)ua * RIDER_KU;
+            rider_gemm(p.V + (size_t)strip * Np * 32 + c0 * 32, p.A + (size_t)krow * BLK + c0 * ld, ld, (uz - ua) * RIDER_KU, acc, grp);
         }
-        if (grp == 1) return;
+        if (units > 0) fold_groups();                        // (uniform over the workgroup)
+        if (grp != 0) return;
         double* P = p.part_out + rider_part_off(ch, nstrips, strip);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v2d o = v2d{acc[0][n][i], acc[1][n][i]};
-                if (j1 > jm) o += *reinterpret_cast<const v2d*>(Rl + G::col_of(wc, n, i, lane) * 32 + G::row_of(0, 0, lane));
+                if (units > 0) o += *rl_at(n, i);
                 *reinterpret_cast<v2d*>(P + (size_t)G::col_of(wc, n, i, lane) * 32 + G::row_of(0, 0, lane)) = o;
             }
         RTRACE_MAX(k, 3);
         return;
     }
     // ---------------- S_k
-    const int strip = blockIdx.x;
+    const int strip = p.efirst ? (int)blockIdx.x - nE : (int)blockIdx.x;
     const int r16 = lane & 15, q = lane >> 4;
     if (tid == 0) {
         *(volatile lds_int_t*)&ready[0] = 0;
         *(volatile lds_int_t*)&ready[1] = 0;
     }
-    // (1) residual of block row k in the strip-GEMM layout, the two groups side by side: group 0 takes the partial sums of slots
-    // 0..3 and block k-2 (k = 1: block 0), group 1 slots 4..7 and block k-1; their sum goes through Rl in that order
+    // (1) residual of block row k in the strip-GEMM layout, the groups side by side: group g takes the partial sums of its
+    // RIDER_MAX_CH / NG slots and its share of the columns of blocks k-2, k-1 (k = 1: block 0); the sum goes through Rl in group order
     if (p.nslots == 0) {
-        if (grp == 0) rider_kstar_tile(acc, p.Xsc, p.Csc, p.d, Np, p.N, p.Mp, p.kern, p.amp2, k, strip, wc, lane);
+        if (grp == 0) {
+            rider_kstar_tile(acc, p.Xsc, p.Csc, p.d, Np, p.N, p.Mp, p.kern, p.amp2, k, strip, wc, lane);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *rl_at(n, i) = v2d{acc[0][n][i], acc[1][n][i]};
+        }
     } else {
-        const int s0 = 4 * grp;                              // this group's slots: [s0, min(s0 + 4, nslots))
+        constexpr int SPG = RIDER_MAX_CH / NG;
+        const int s0 = SPG * grp;                            // this group's slots: [s0, min(s0 + SPG, nslots))
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+            for (int n = 0; n < TN; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
         if (s0 < p.nslots) {
             const double* P0 = p.part_in + rider_part_off(0, nstrips, strip) + G::row_of(0, 0, lane);
             const size_t sstride = rider_part_off(1, nstrips, 0);
-            v2d t[4][2][4];
+            v2d t[SPG][TN][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {                    // four slots per memory round trip, added in slot order
+            for (int u = 0; u < SPG; ++u) {                  // the group's slots in one memory round trip, added in slot order
                 const double* Ps = P0 + (size_t)min(s0 + u, p.nslots - 1) * sstride;
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < TN; ++n)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) t[u][n][i] = *reinterpret_cast<const v2d*>(Ps + (size_t)G::col_of(wc, n, i, lane) * 32);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < SPG; ++u) {
                 if (u == 0) {
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < TN; ++n)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             acc[0][n][i] = t[0][n][i][0];
@@ -256,7 +289,7 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
                         }
                 } else if (s0 + u < p.nslots) {
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < TN; ++n)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             acc[0][n][i] += t[u][n][i][0];
@@ -265,28 +298,18 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
                 }
             }
         }
-        const int jb = k >= 2 ? k - 2 + grp : (grp == 0 ? 0 : -1);   // the block of V this group multiplies
+        const int c0 = max(k - 2, 0) * BLK, share = min(k, 2) * BLK / NG;   // this group's columns: [c0 + grp·share, + share)
 #ifdef BOSS_EXPERIMENTS
         if (!(p.exp & 2))
 #endif
-        if (jb >= 0)
-            rider_gemm(p.V + (size_t)strip * Np * 32 + (size_t)jb * BLK * 32, p.A + (size_t)k * BLK + (size_t)jb * BLK * ld, ld, BLK, acc, grp);
-    }
-    if (grp == 0) {
+        rider_gemm(p.V + (size_t)strip * Np * 32 + (size_t)(c0 + grp * share) * 32, p.A + (size_t)k * BLK + (size_t)(c0 + grp * share) * ld, ld, share, acc, grp);
+        fold_groups();
+        if (grp == 0) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < TN; ++n)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(Rl + G::col_of(wc, n, i, lane) * 32 + G::row_of(0, 0, lane)) = v2d{acc[0][n][i], acc[1][n][i]};
-    }
-    __syncthreads();
-    if (grp == 1 && p.nslots != 0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v2d* dst = reinterpret_cast<v2d*>(Rl + G::col_of(wc, n, i, lane) * 32 + G::row_of(0, 0, lane));
-                *dst = *dst + v2d{acc[0][n][i], acc[1][n][i]};
-            }
+                for (int i = 0; i < 4; ++i) *rl_at(n, i) = *rl_at(n, i) + v2d{acc[0][n][i], acc[1][n][i]};
+        }
     }
     // (2) v · z of block k-2 (its z entries are final, see above)
     double* Vst = p.V + (size_t)strip * Np * 32;             // + row * 32 + candidate
@@ -351,7 +374,7 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
         for (int i = 0; i < 4; ++i) Vs[(size_t)(k * BLK + jb * 16 + q + 4 * i) * 32 + r16] = t[i];
     };
     double ssq = 0.0;
-    if (grp == 1) {
+    if (wave >= 4) {
     } else if (role == 0) {
         v4d a5[TRSM_NA];
         double lv[TRSM_NA][TRSM_NA][4], iv[TRSM_NA][4];
@@ -439,7 +462,7 @@ __global__ __launch_bounds__(RIDER_THREADS) void rider_step_kernel(RiderStep p) 
     // Σ v² of this block per candidate: the four column groups of a wave, then the two waves of the pair
     ssq += __shfl_xor(ssq, 16);
     ssq += __shfl_xor(ssq, 32);
-    if (grp == 0 && lane < 16) red[half][role][lane] = ssq;
+    if (wave < 4 && lane < 16) red[half][role][lane] = ssq;
     __syncthreads();
     if (tid < 32) p.part_ss[(size_t)k * p.Mp + strip * 32 + tid] = red[tid >> 4][0][tid & 15] + red[tid >> 4][1][tid & 15];
     RTRACE_MAX(k, 2);
