@@ -207,11 +207,33 @@ static int ctx_init(Ctx* c) {
         // Panel chain on the highest-priority stream, bulk trailing updates on the lowest-priority one.
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        // BOSS_CU_MASK=1 (experiment, tools/cumask_check.py): the resident chain and strips on reserved CUs, everything else on the
+        // complement.  Mask bit b enables CU position b / 8 of XCD b % 8 (tools/cumask_probe.hip); streams with EQUAL masks share a
+        // hardware queue (a kernel behind a resident one on it never starts), so all four masks differ.
+        static const int cu_mask = getenv("BOSS_CU_MASK") ? atoi(getenv("BOSS_CU_MASK")) : 0;
+        if (cu_mask) {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, c->device));
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            auto make = [&](hipStream_t* st, int lo, int hi) {   // CUs [lo, hi) in mask-bit order
+                std::vector<uint32_t> m(words, 0u);
+                for (int b = lo; b < hi && b < ncu; ++b) m[b / 32] |= 1u << (b % 32);
+                return hipExtStreamCreateWithCUMask(st, (uint32_t)words, m.data());
+            };
+            HIPCHK(make(&c->chain_stream, 0, 16));           // two CU positions on every XCD (the chain has two workgroups)
+            HIPCHK(make(&c->strip_stream, 16, 32));          // two more (eight strip workgroups)
+            HIPCHK(make(&c->own_stream, 32, ncu));
+            HIPCHK(make(&c->side_stream, cu_mask >= 2 ? 40 : 32, cu_mask >= 2 ? ncu : ncu - 8));
+            c->stream = c->own_stream;
+            std::fprintf(stderr, "[bosship] BOSS_CU_MASK=%d: chain on CU bits 0-15, strips on 16-31, main stream on 32-%d, side stream %d-%d\n",
+                         cu_mask, ncu - 1, cu_mask >= 2 ? 40 : 32, (cu_mask >= 2 ? ncu : ncu - 8) - 1);
+        } else {
         HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest));
         c->stream = c->own_stream;
         HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
         HIPCHK(hipStreamCreateWithPriority(&c->chain_stream, hipStreamNonBlocking, greatest));
         HIPCHK(hipStreamCreateWithPriority(&c->strip_stream, hipStreamNonBlocking, greatest));
+        }
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));

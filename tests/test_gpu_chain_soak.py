@@ -186,3 +186,24 @@ def test_updates_beside_foreign_kernels_are_bit_identical(api, N):
     assert not changed, f"{len(changed)} of 500 updates differ from the undisturbed result: {changed[:4]} (fallbacks {fallbacks})"
     assert fallbacks <= 2, fallbacks                              # at most: chain off once, then at most one gate fallback (each is taken once per process / context)
     print(f"N={N}: foreign loops {loops}, fallbacks {fallbacks}, chain switched off {chain_off}")
+
+
+def test_cu_masked_streams_are_bit_identical():
+    """The round-3 experiment that once gave wrong factors: chain and strips on reserved CUs, the update's other kernels on the
+    complement (hipExtStreamCreateWithCUMask, BOSS_CU_MASK=1), i.e. every hand-off of the protocol crosses hardware queues AND CU
+    sets.  A run with masked streams must reproduce the unmasked run bit for bit — logpdf of every update, the factor of the first and
+    last ones, the fused update + acquisition — without a fallback (tools/cumask_check.py exits non-zero on any difference).  The
+    masks are fixed when a context is created, hence the two child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NS="1408,4096", NHASH="2", LONG="90")
+    env.pop("BOSS_CU_MASK", None)
+    tool = os.path.join(root, "tools", "cumask_check.py")
+    rec = subprocess.run([sys.executable, tool, "record", "12"], env=env, capture_output=True, text=True, timeout=300)
+    assert rec.returncode == 0, rec.stdout[-2000:] + rec.stderr[-2000:]
+    chk = subprocess.run([sys.executable, tool, "check", "12"], env=dict(env, BOSS_CU_MASK="1"), capture_output=True, text=True, timeout=300)
+    assert chk.returncode == 0, chk.stdout[-2000:] + chk.stderr[-2000:]
+    assert "MISMATCHES: 0" in chk.stdout and "BOSS_CU_MASK=1" in chk.stderr, chk.stdout[-2000:] + chk.stderr[-500:]
+    assert "fallbacks so far 0" in chk.stdout, chk.stdout[-2000:]
