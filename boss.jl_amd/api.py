@@ -39,6 +39,8 @@ SIGNATURES = {
     "boss_ngp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_ggp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_void_p)]),
     "boss_ggp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, C.c_double, C.c_int, _c_dp]),
+    "boss_ggp_loglike_grad": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
+    "boss_ggp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
                               _c_ucp, C.POINTER(C.c_void_p), _c_dp]),
     "boss_gp_set_y": (C.c_int, [C.c_void_p, _c_dp]),
@@ -413,6 +415,30 @@ class GradGP(GP):
             self.logpdf = out.value
             return out.value
         return None
+
+    def loglike_grad(self):
+        """(logpdf, grad[d+3]) at the parameters of the last update: gradient w.r.t. (lengthscale[d], amplitude, noise_std,
+        grad_noise_std) — what ForwardDiff yields through data_loglike (gradient_gp.jl:367-397) inside OptimizationMAP."""
+        out = C.c_double(0.0)
+        grad = np.zeros(self.d + 3)
+        _check(load_library().boss_ggp_loglike_grad(self._h, C.byref(out), _dp(grad)))
+        return out.value, grad
+
+    def append(self, X_new, y_new, dY_new) -> float:
+        """augment_dataset! + the posterior at unchanged hyper-parameters (the augmented system is rebuilt and factorised, as in the
+        reference): X_new d×m (or a length-d vector), y_new m, dY_new d×m.  Returns the logpdf of all n + m points."""
+        X_new = _f64(np.asarray(X_new, dtype=np.float64).reshape(self.d, -1), 2)
+        m = X_new.shape[1]
+        y_new = _f64(np.asarray(y_new).reshape(-1), 1)
+        dY_new = np.asfortranarray(np.asarray(dY_new, dtype=np.float64).reshape(self.d, -1))
+        if y_new.shape[0] != m or dY_new.shape != (self.d, m):
+            raise ValueError("y_new must have one entry and dY_new one column per new point")
+        out = C.c_double(0.0)
+        _check(load_library().boss_ggp_append(self._h, m, _dp(X_new), _dp(y_new), dY_new.ctypes.data_as(_c_dp), C.byref(out)))
+        self.n += m
+        self.N = self.n * (1 + self.d)
+        self.logpdf = out.value
+        return out.value
 
 
 class GibbsGP(GP):

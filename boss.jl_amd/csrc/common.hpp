@@ -85,6 +85,14 @@ __device__ __forceinline__ double kappa_second_r2(int kern, double r2) {
     return (25.0 / 3.0) * exp(-2.23606797749979 * r);
 }
 
+// q(r) = g'(r)/r (likelihood gradient of the gradient-observation model: ∂/∂λ of the second-derivative block)
+__device__ __forceinline__ double kappa_third_r2(int kern, double r2) {
+    if (kern == KERN_SQEXP) return -exp(-0.5 * r2);
+    double r = sqrt(r2);
+    if (kern == KERN_MATERN32) return -5.196152422706632 * (1.0 + 1.7320508075688772 * r) * exp(-1.7320508075688772 * r) / (r2 * r);
+    return -(25.0 * 2.23606797749979 / 3.0) * exp(-2.23606797749979 * r) / r;
+}
+
 __device__ __forceinline__ double normcdf_dev(double z) {   // StatsFuns.normcdf = erfc(-z/√2)/2
     return 0.5 * erfc(-z * 0.7071067811865476);
 }

@@ -203,6 +203,133 @@ __global__ __launch_bounds__(256) void aug_gram_kernel(const double* __restrict_
     }
 }
 
+// One entry of the augmented matrix AND its derivatives w.r.t. the lengthscales (dl[m] = ∂entry/∂λ_m), same arguments and same
+// perturbation rule as aug_entry (the value block at the points as given, the derivative blocks at xj + 1e-8 when xi ≈ xj).  With
+// u = xi − xj, s = u ⊘ λ², w_m = −u_m²/λ_m³ and the profiles h = κ'/r, g = h'/r, q = g'/r:
+//   value            α² κ                 ∂/∂λ_m = α² h w_m
+//   (0, m') / (l, 0) ∓α² h s              ∂/∂λ_m = ∓α² (g w_m s − 2 h s δ/λ_m)
+//   (l, l')          −α² (g s_l s_l' + h δ_ll'/λ_l²)
+//                                         ∂/∂λ_m = −α² (q w_m s_l s_l' − 2 g s_l s_l' (δ_lm + δ_l'm)/λ_m + g w_m δ_ll'/λ_l² − 2 h δ_ll' δ_lm/λ_l³)
+// (checked against finite differences of the likelihood in tests/)
+__device__ __forceinline__ double aug_entry_dlam(int kern, double amp2, int d, const double* il, const double* xi, int si,
+                                                 const double* xj, int sj, int lr, int lc, double* dl) {
+    double du2 = 0.0, ni = 0.0, nj = 0.0, r2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double a = xi[k * si], b = xj[k * sj], u = a - b, t = u * il[k];
+        du2 = __builtin_fma(u, u, du2);
+        ni = __builtin_fma(a, a, ni);
+        nj = __builtin_fma(b, b, nj);
+        r2 = __builtin_fma(t, t, r2);
+    }
+    if (lr == 0 && lc == 0) {
+        const double h0 = amp2 * kappa_prime_over_r_r2(kern, r2);
+        for (int k = 0; k < d; ++k) {
+            const double u = xi[k * si] - xj[k * sj];
+            dl[k] = -h0 * u * u * il[k] * il[k] * il[k];
+        }
+        return amp2 * kappa_r2(kern, r2);
+    }
+    double eps = 0.0;
+    if (du2 <= ISAPPROX_RTOL2 * fmax(ni, nj)) {
+        eps = MIN_PARAM_VALUE;
+        r2 = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double t = (xi[k * si] - (xj[k * sj] + eps)) * il[k];
+            r2 = __builtin_fma(t, t, r2);
+        }
+    }
+    const double h = kappa_prime_over_r_r2(kern, r2), g = kappa_second_r2(kern, r2);
+    if (lr == 0 || lc == 0) {
+        const int m = (lr == 0 ? lc : lr) - 1;
+        const double sgn = (lr == 0) ? -amp2 : amp2;
+        const double s = (xi[m * si] - (xj[m * sj] + eps)) * il[m] * il[m];
+        for (int k = 0; k < d; ++k) {
+            const double u = xi[k * si] - (xj[k * sj] + eps), w = -u * u * il[k] * il[k] * il[k];
+            dl[k] = sgn * g * w * s;
+        }
+        dl[m] += sgn * (-2.0 * h * s * il[m]);
+        return sgn * h * s;
+    }
+    const int l = lr - 1, m = lc - 1;
+    const double q = kappa_third_r2(kern, r2);
+    const double sl = (xi[l * si] - (xj[l * sj] + eps)) * il[l] * il[l];
+    const double sm = (xi[m * si] - (xj[m * sj] + eps)) * il[m] * il[m];
+    const double diag = (l == m) ? il[l] * il[l] : 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double u = xi[k * si] - (xj[k * sj] + eps), w = -u * u * il[k] * il[k] * il[k];
+        dl[k] = -amp2 * w * __builtin_fma(q * sl, sm, g * diag);
+    }
+    dl[l] += 2.0 * amp2 * g * sl * sm * il[l];
+    dl[m] += 2.0 * amp2 * g * sl * sm * il[m];
+    if (l == m) dl[l] += 2.0 * amp2 * h * il[l] * il[l] * il[l];
+    return -amp2 * __builtin_fma(g * sl, sm, h * diag);
+}
+
+// Likelihood gradient of the gradient-observation model, contraction part: lower 64×64 tiles like aug_gram_kernel,
+//   out[tile][0..d-1] = Σ w G_ab ∂K_ab/∂λ_m ,  out[tile][d] = Σ w G_ab K⁰_ab (noise-free entries) ,
+//   out[tile][d+1] = Σ_{a value row} G_aa ,  out[tile][d+2] = Σ_{a derivative row} G_aa ,
+// w = 1 below the diagonal (the pair counts twice in ½ Σ_ab), ½ on it;  G = a aᵀ − K⁻¹ with a summed from its nch partials.
+__global__ __launch_bounds__(256) void aug_llgrad_tile_kernel(const double* __restrict__ Xraw, int ldx, int d, int n, int N, int Np, int kern,
+                                                              const double* __restrict__ hyp, const double* __restrict__ invlam,
+                                                              const double* __restrict__ Kinv, int ldk, const double* __restrict__ apart,
+                                                              int nch, double* __restrict__ out) {
+    __shared__ double xa[AUG_MAX_D][64], xb[AUG_MAX_D][64], il[AUG_MAX_D], ab[64], red[256];
+    __shared__ int la[64], lb[64];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    while (bi * (bi + 1) / 2 > t) --bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    if (tid < 128) {
+        const int c = tid & 63, obs = (tid < 64 ? bi : bj) * 64 + c;
+        const int l = obs < N ? obs / n : -1, pt = obs < N ? obs - l * n : 0;
+        if (tid < 64) la[c] = l; else lb[c] = l;
+        for (int k = 0; k < d; ++k) (tid < 64 ? xa : xb)[k][c] = Xraw[(size_t)k * ldx + pt];
+        if (tid >= 64) {
+            double s = 0.0;
+            for (int ch = 0; ch < nch; ++ch) s += apart[(size_t)ch * Np + obs];
+            ab[c] = s;
+        }
+    }
+    if (tid >= 128 && tid < 128 + d) il[tid - 128] = invlam[tid - 128];
+    __syncthreads();
+    const double amp2 = hyp[0];
+    const int r = tid & 63, cg = tid >> 6, a = bi * 64 + r;
+    double aa = 0.0;
+    for (int ch = 0; ch < nch; ++ch) aa += apart[(size_t)ch * Np + a];
+    double S[AUG_MAX_D + 3];
+#pragma unroll
+    for (int m = 0; m < AUG_MAX_D + 3; ++m) S[m] = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < 16; ++c) {
+        const int cc = cg * 16 + c, b = bj * 64 + cc;
+        if (a < b || a >= N || b >= N) continue;
+        const double G = aa * ab[cc] - Kinv[(size_t)b * ldk + a];
+        double dl[AUG_MAX_D];
+        const double v = aug_entry_dlam(kern, amp2, d, il, &xb[0][cc], 64, &xa[0][r], 64, lb[cc], la[r], dl);
+        const double w = (a == b) ? 0.5 * G : G;
+#pragma unroll
+        for (int m = 0; m < AUG_MAX_D; ++m)
+            if (m < d) S[m] = __builtin_fma(w, dl[m], S[m]);
+        S[AUG_MAX_D] = __builtin_fma(w, v, S[AUG_MAX_D]);
+        if (a == b) S[AUG_MAX_D + (la[r] == 0 ? 1 : 2)] += G;
+    }
+    for (int m = 0; m < d + 3; ++m) {
+        double v = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < AUG_MAX_D + 3; ++mm)
+            if (mm == (m < d ? m : AUG_MAX_D + (m - d))) v = S[mm];
+        __syncthreads();
+        red[tid] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) out[(size_t)t * (d + 3) + m] = red[0];
+    }
+}
+
 // Cross-covariances of `_build_cross_cov` for every candidate, written where the substitution kernels
 // expect their right-hand side: out[tile][row][BN] (the V slabs of predict_kernel<G, true>, or the residual
 // array of the few-candidates path).  One training observation per thread; padding rows = 0.

@@ -99,30 +99,69 @@ class HipGradientMAP:
         tot = np.where(np.isfinite(tot), tot, -np.inf)
         return tot, gl, ga, gs
 
+    def _objective_gradient_model(self, model, prior_ll, data, plist):
+        """The same for a HipGradientGaussianProcess (values + gradients): per start and output one boss_ggp_update and one
+        boss_ggp_loglike_grad on resident handles (an augmented factorisation fills the device on its own); a fourth parameter group,
+        the gradient noise σ_∂ (what ForwardDiff yields through gradient_gp.jl:367-397 inside OptimizationMAP)."""
+        S = len(plist)
+        d, P = plist[0].lengthscales.shape
+        tot = np.array([prior_ll(p) for p in plist], dtype=float)
+        gl, ga, gs, gd = np.zeros((S, d, P)), np.zeros((S, P)), np.zeros((S, P)), np.zeros((S, P))
+        llg = model.data_loglike_grad(data)
+        try:
+            for k, p in enumerate(plist):
+                ll, g = llg(p)
+                tot[k] += ll
+                if not np.isfinite(ll):
+                    continue
+                gl[k], ga[k], gs[k], gd[k] = g.lengthscales, g.amplitudes, g.noise_std, g.grad_noise_std
+                for i in range(P):
+                    gl[k, :, i] += np.atleast_1d(model.lengthscale_priors[i].grad_logpdf(p.lengthscales[:, i]))
+                    ga[k, i] += model.amplitude_priors[i].grad_logpdf(p.amplitudes[i])
+                    gs[k, i] += model.noise_std_priors[i].grad_logpdf(p.noise_std[i])
+                    gd[k, i] += model.grad_noise_std_priors[i].grad_logpdf(p.grad_noise_std[i])
+        finally:
+            for h in llg.handles:
+                h.close()
+        tot = np.where(np.isfinite(tot), tot, -np.inf)
+        return tot, gl, ga, gs, gd
+
     def estimate_parameters(self, problem: BossProblem, options: BossOptions = BossOptions(), return_all: bool = False):
-        model: HipGaussianProcess = problem.model
-        if model.parametric is not None:
+        model = problem.model
+        grad_model = hasattr(model, "grad_noise_std_priors")        # HipGradientGaussianProcess (gradient_gp.py)
+        if not grad_model and model.parametric is not None:
             raise NotImplementedError("HipGradientMAP treats the prior mean as fixed; use HipBatchedMAP for Semiparametric models")
         data = problem.data
         rng = np.random.default_rng(dist_util.shared_seed(self.seed, self.group))     # the same starts on every rank
         sampler, prior_ll = model.params_sampler(), model.params_loglike()
         if self.starts is not None:
-            starts: List[HipGPParams] = list(self.starts)
+            starts = list(self.starts)
         else:
             starts = [sampler(rng) for _ in range(self.multistart)]                      # same stream on every rank
         nstart = len(starts)
         rank, world = dist_util.rank_world(self.group)
         lo, hi = dist_util.shard_range(nstart, rank, world)
         P = data.Y.shape[0]
-        free_l = np.array([not isinstance(pr, (Dirac, MvDirac)) for pr in model.lengthscale_priors])
-        free_a = np.array([not isinstance(pr, Dirac) for pr in model.amplitude_priors])
-        free_s = np.array([not isinstance(pr, Dirac) for pr in model.noise_std_priors])
+        # the parameter groups the ascent moves, and which of their entries are free (a Dirac prior fixes its parameter)
+        free = [np.array([not isinstance(pr, (Dirac, MvDirac)) for pr in model.lengthscale_priors])[None, :],
+                np.array([not isinstance(pr, Dirac) for pr in model.amplitude_priors]),
+                np.array([not isinstance(pr, Dirac) for pr in model.noise_std_priors])]
+        if grad_model:
+            free.append(np.array([not isinstance(pr, Dirac) for pr in model.grad_noise_std_priors]))
+            parts_of = lambda p: [p.lengthscales, p.amplitudes, p.noise_std, p.grad_noise_std]
+            remake = lambda p, q: type(p)(q[0], q[1], q[2], q[3])
+            objective = lambda pl: (lambda r: (r[0], list(r[1:])))(self._objective_gradient_model(model, prior_ll, data, pl))
+        else:
+            parts_of = lambda p: [p.lengthscales, p.amplitudes, p.noise_std]
+            remake = lambda p, q: HipGPParams(q[0], q[1], q[2], p.theta)
+            objective = lambda pl: (lambda r: (r[0], list(r[1:])))(self._objective_batch(model, prior_ll, data, pl))
         results = []
         if hi > lo:
             # every start runs the same backtracking ascent it would run alone; the starts advance in lockstep so that each
             # round's trial points are evaluated by ONE batched device call per output
             ps = [starts[k] for k in range(lo, hi)]
-            f, gl, ga, gs = self._objective_batch(model, prior_ll, data, ps)
+            f, grads = objective(ps)
+            grads = [np.array(g) for g in grads]
             n = len(ps)
             step = np.full(n, self.step0)
             its = np.zeros(n, dtype=int)
@@ -130,24 +169,23 @@ class HipGradientMAP:
             while alive.any():
                 idx, trial = [], []
                 for k in np.flatnonzero(alive):
-                    p = ps[k]
+                    parts = parts_of(ps[k])
                     # ascent direction in log-space: ∂f/∂log θ = θ ∂f/∂θ ; fixed (Dirac) parameters do not move
-                    dl = np.where(free_l[None, :], p.lengthscales * gl[k], 0.0)
-                    da = np.where(free_a, p.amplitudes * ga[k], 0.0)
-                    ds = np.where(free_s, p.noise_std * gs[k], 0.0)
-                    nrm = math.sqrt(float((dl * dl).sum() + (da * da).sum() + (ds * ds).sum()))
+                    dirs = [np.where(fr, q * g[k], 0.0) for q, g, fr in zip(parts, grads, free)]
+                    nrm = math.sqrt(float(sum((dq * dq).sum() for dq in dirs)))
                     if nrm < 1e-10:
                         alive[k] = False
                         continue
                     idx.append(k)
-                    trial.append(HipGPParams(p.lengthscales * np.exp(step[k] * dl / nrm), p.amplitudes * np.exp(step[k] * da / nrm),
-                                             p.noise_std * np.exp(step[k] * ds / nrm), p.theta))
+                    trial.append(remake(ps[k], [q * np.exp(step[k] * dq / nrm) for q, dq in zip(parts, dirs)]))
                 if not idx:
                     break
-                fq, glq, gaq, gsq = self._objective_batch(model, prior_ll, data, trial)
+                fq, gq = objective(trial)
                 for j, k in enumerate(idx):
                     if fq[j] > f[k]:
-                        ps[k], f[k], gl[k], ga[k], gs[k] = trial[j], fq[j], glq[j], gaq[j], gsq[j]
+                        ps[k], f[k] = trial[j], fq[j]
+                        for g, gn in zip(grads, gq):
+                            g[k] = gn[j]
                         step[k] = min(step[k] * 1.6, 2.0)
                         its[k] += 1
                         if its[k] >= self.iters:
@@ -165,10 +203,13 @@ class HipGradientMAP:
         if world == 1:
             return MAPParams(best[1], best_v)
         mine = best[1] if best and best[0] == gi else None
-        flat = None if mine is None else np.concatenate([mine.lengthscales.reshape(-1, order="F"), mine.amplitudes, mine.noise_std])
-        d = data.X.shape[0]
-        flat = dist_util.broadcast_array(flat, (d * P + 2 * P,), dist_util.owner_of_index(gi, nstart, world), self.group)
-        return MAPParams(HipGPParams(flat[:d * P].reshape(d, P, order="F"), flat[d * P:d * P + P], flat[d * P + P:]), best_v)
+        shapes = [np.shape(q) for q in parts_of(starts[0])]
+        sizes = [int(np.prod(sh)) for sh in shapes]
+        flat = None if mine is None else np.concatenate([np.asarray(q).reshape(-1, order="F") for q in parts_of(mine)])
+        flat = dist_util.broadcast_array(flat, (sum(sizes),), dist_util.owner_of_index(gi, nstart, world), self.group)
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        parts = [flat[offs[i]:offs[i + 1]].reshape(shapes[i], order="F") for i in range(len(shapes))]
+        return MAPParams(remake(starts[0], parts), best_v)
 
 
 @dataclass

@@ -79,7 +79,12 @@ class HipGradientGPPosteriorSlice(HipGaussianProcessPosteriorSlice):
     def _unavailable(self, *a, **k):
         raise NotImplementedError("not defined for gradient-observation posteriors")
 
-    mean_and_cov = cov = append = _unavailable               # (mean_and_var_grad: inherited — boss_gp_predict_grad takes these posteriors)
+    mean_and_cov = cov = _unavailable                        # (mean_and_var_grad: inherited — boss_gp_predict_grad takes these posteriors)
+
+    def append(self, x, y, dy) -> float:
+        """augment_dataset! (src/types/problem.jl:191-198) on the fitted slice: new points with values and gradients, hyper-parameters
+        unchanged (boss_ggp_append: the augmented system is rebuilt and factorised, as in the reference)."""
+        return self.gp.append(x, y, dy)
 
 
 @dataclass
@@ -134,6 +139,28 @@ class HipGradientGaussianProcess:
             return tot
         ll.handles = gps
         return ll
+
+    def data_loglike_grad(self, data: GradientData):
+        """data_loglike with its gradient w.r.t. (λ, α, σ, σ_∂) — what ForwardDiff yields through gradient_gp.jl:367-397 inside
+        OptimizationMAP (src/model_fitters/optimization.jl:146-164): p -> (ℓ, HipGradientGPParams of partial derivatives), per
+        output one boss_ggp_update + boss_ggp_loglike_grad on a resident handle.  Non-PD: (-Inf, zeros)."""
+        gps = [api.GradGP(data.X, data.Y[i], data.dY[i], self.kernel, self.device) for i in range(data.Y.shape[0])]
+
+        def llg(p: HipGradientGPParams):
+            d, P = p.lengthscales.shape
+            gl, ga, gs, gd = np.zeros((d, P)), np.zeros(P), np.zeros(P), np.zeros(P)
+            tot = 0.0
+            for i, g in enumerate(gps):
+                try:
+                    g.update(p.lengthscales[:, i], p.amplitudes[i], p.noise_std[i], p.grad_noise_std[i])
+                except api.PosDefException:
+                    return -math.inf, HipGradientGPParams(np.zeros((d, P)), np.zeros(P), np.zeros(P), np.zeros(P))
+                ll, gr = g.loglike_grad()
+                tot += ll
+                gl[:, i], ga[i], gs[i], gd[i] = gr[:d], gr[d], gr[d + 1], gr[d + 2]
+            return tot, HipGradientGPParams(gl, ga, gs, gd)
+        llg.handles = gps
+        return llg
 
     def data_loglike_batch(self, data: GradientData, samples: Sequence[HipGradientGPParams]) -> np.ndarray:
         """`loglike.(samples)` (src/model_fitters/sampling.jl:64,77) — what HipBatchedMAP calls; the augmented

@@ -706,6 +706,26 @@ function data_loglike(m::HipGradientGaussianProcess, data::BOSS.GradientData)
     h = Handle(ggp_create(m, data, 1))            # per-output likelihood of the sliced model (gradient_gp.jl:367-397)
     return p -> try ggp_update(h.h, p, 1) catch e; e isa PosDefException ? -Inf : rethrow() end
 end
+"""
+data_loglike with its gradient, for gradient-based fitters (what ForwardDiff yields through gradient_gp.jl:367-397 inside
+OptimizationMAP, src/model_fitters/optimization.jl:146-164): p -> (ℓ, (∂ℓ/∂λ (x_dim), ∂ℓ/∂α, ∂ℓ/∂σ, ∂ℓ/∂σ_∂)) of the sliced model.
+"""
+function data_loglike_grad(m::HipGradientGaussianProcess, data::BOSS.GradientData)
+    h = Handle(ggp_create(m, data, 1)); d = size(data.X, 1)
+    return function (p)
+        ggp_update(h.h, p, 1)
+        lp = Ref{Cdouble}(); g = Vector{Float64}(undef, d + 3)
+        GC.@preserve h check(ccall((:boss_ggp_loglike_grad, lib), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ptr{Cdouble}), h.h, lp, g))
+        return lp[], (g[1:d], g[d + 1], g[d + 2], g[d + 3])
+    end
+end
+"augment_dataset! (src/types/problem.jl:191-198) for a fitted gradient-observation slice: new points with values and gradients, same hyper-parameters."
+function augment!(post::HipPosteriorSlice, X_new::AbstractMatrix{<:Real}, y_new::AbstractVector{<:Real}, dY_new::AbstractMatrix{<:Real})
+    lp = Ref{Cdouble}()
+    GC.@preserve post check(ccall((:boss_ggp_append, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
+        post.h.h, size(X_new, 2), Matrix{Float64}(X_new), Vector{Float64}(y_new), Matrix{Float64}(dY_new), lp))
+    return lp[]
+end
 # ---------------------------------------------------------------- NonstationaryGP (Gibbs kernel)
 # The latent models stay BOSS's own (ParametrizedGP posteriors or constants); only their values cross the ABI.
 struct HipNonstationaryPosterior <: BOSS.ModelPosteriorSlice{BOSS.NonstationaryGP}

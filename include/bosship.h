@@ -146,7 +146,8 @@ int boss_gp_get_factor(const boss_gp_t* gp, double* L_out, double* z_out);
  * k* from _build_cross_cov :221-243; mean_Xs must be NULL), boss_gp_get_factor, boss_acq_ei, boss_acq_ei_moments
  * boss_gp_predict_grad and boss_acq_ei_grad (the gradients ForwardDiff pushes through :334-361 inside OptimizationAM,
  * src/acquisition_maximizers/optimization.jl:36,89-118; mean_Xs / mean_grad must be NULL; var is max(0, .), its gradient that of
- * the unclipped expression) and boss_gp_free work on it; the entry points that assume value-only observations (boss_gp_update,
+ * the unclipped expression) and boss_gp_free work on it; boss_ggp_loglike_grad and boss_ggp_append are its own forms of the
+ * likelihood gradient and of augment_dataset!; the entry points that assume value-only observations (boss_gp_update,
  * boss_gp_set_y, boss_gp_append, boss_gp_reserve, boss_gp_predict_cov, boss_gp_loglike_grad, boss_track_create) return
  * BOSS_E_INVALID.
  * Limits: d <= 16, n(1+d) <= 46080. */
@@ -154,6 +155,17 @@ int boss_ggp_create(int device, int kernel, int d, int n, const double* X, const
                     boss_gp_t** out);
 int boss_ggp_update(boss_gp_t* gp, const double* lengthscale, double amplitude, double noise_std,
                     double grad_noise_std, int flags, double* logpdf_out);
+/* data_loglike of the gradient-observation model with its gradient, as OptimizationMAP takes it through ForwardDiff
+ * (src/model_fitters/optimization.jl:146-164 through gradient_gp.jl:367-397): at the parameters of the last boss_ggp_update,
+ *   grad_out[d + 3] = d logpdf / d(lengthscale[0..d-1], amplitude, noise_std, grad_noise_std)
+ * (= 1/2 sum_ab (a a' - K^-1)_ab dK_ab/dtheta over the matrix `cholesky(Symmetric(K))` sees, a = K^-1 y~; the lengthscale derivatives
+ * of the second-derivative block need the third radial profile of the kernel).  logpdf_out may be NULL. */
+int boss_ggp_loglike_grad(boss_gp_t* gp, double* logpdf_out, double* grad_out);
+/* augment_dataset! (src/types/problem.jl:191-198) + the posterior at unchanged hyper-parameters: n_new further points with values
+ * and gradients (X_new d×n_new, y_new n_new, dY_new d×n_new column-major).  New observations land inside every block of the
+ * ordering [y; dy/dx_1; ...; dy/dx_d], so — as in the reference — the augmented system is rebuilt and factorised again; the handle
+ * stays the same object.  logpdf_out: logpdf of all n + n_new points.  Needs a fitted handle (BOSS_E_NOT_FITTED otherwise). */
+int boss_ggp_append(boss_gp_t* gp, int n_new, const double* X_new, const double* y_new, const double* dY_new, double* logpdf_out);
 
 /* ---- nonstationary posteriors -----------------------------------------------------
  * Replaces: NonstationaryGP — NonstationaryKernel / gibbs_kernel (src/models/nonstationary_gp/nonstationary_gp.jl:61-107),

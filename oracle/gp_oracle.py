@@ -815,6 +815,96 @@ def gradient_gp_mean_and_var_grad(post: "GradientGPPosterior", Xs):
     return mu, var, dmu, dvar
 
 
+def kappa_third(kernel: int, r: np.ndarray) -> np.ndarray:
+    """q(r) = g'(r)/r with g = kappa_second:  SqExp −e^{-r²/2};  Matern52 −(25√5/3) e^{-√5 r}/r;
+    Matern32 −3√3 (1+√3 r) e^{-√3 r}/r³.  (Only ever evaluated at r > 0: coincident points are perturbed like in
+    `_kernel_and_derivs`.)"""
+    r = np.asarray(r, dtype=np.float64)
+    if kernel == SQEXP:
+        return -np.exp(-0.5 * r * r)
+    if kernel == MATERN52:
+        return -(25.0 * _SQRT5 / 3.0) * np.exp(-_SQRT5 * r) / r
+    if kernel == MATERN32:
+        return -3.0 * _SQRT3 * (1.0 + _SQRT3 * r) * np.exp(-_SQRT3 * r) / r ** 3
+    raise ValueError(f"unknown kernel id {kernel}")
+
+
+def _kernel_derivs_dlam(kernel: int, lam: np.ndarray, amp2: float, xi: np.ndarray, xj: np.ndarray):
+    """∂/∂λ_m of the four blocks `_kernel_and_derivs` returns, m = 0..d-1 in the leading axis:
+    (dk[m], d(∂k/∂xi)[m, l], d(∂k/∂xj)[m, l], d(∂²k)[m, l, l']).  With u = xi − xj (perturbed for the derivative blocks when
+    xi ≈ xj), s = u ⊘ λ², w_m = −u_m²/λ_m³ (= r ∂r/∂λ_m) and the profiles h = κ'/r, g = h'/r, q = g'/r:
+        ∂k/∂λ_m            = α² h(r₀) w⁰_m                                   (value block: unperturbed points)
+        ∂(α² h s_l)/∂λ_m   = α² (g w_m s_l − 2 h s_l δ_lm/λ_l)
+        ∂(−α²(g s_l s_l' + h δ_ll'/λ_l²))/∂λ_m
+                           = −α² (q w_m s_l s_l' − 2 g s_l s_l' (δ_lm/λ_l + δ_l'm/λ_l') + g w_m δ_ll'/λ_l² − 2 h δ_ll' δ_lm/λ_l³)."""
+    d = len(lam)
+    u0 = xi - xj
+    r0 = float(np.sqrt(np.sum((u0 / lam) ** 2)))
+    dk = amp2 * float(kappa_prime_over_r(kernel, np.float64(r0))) * (-(u0 ** 2) / lam ** 3)
+    u = xi - (xj + MIN_PARAM_VALUE) if _isapprox(xi, xj) else u0
+    r = float(np.sqrt(np.sum((u / lam) ** 2)))
+    h = float(kappa_prime_over_r(kernel, np.float64(r)))
+    g = float(kappa_second(kernel, np.float64(r)))
+    q = float(kappa_third(kernel, np.float64(r)))
+    s = u / lam ** 2
+    w = -(u ** 2) / lam ** 3
+    ddxi = np.zeros((d, d))
+    dd2 = np.zeros((d, d, d))
+    for m in range(d):
+        ddxi[m] = amp2 * g * w[m] * s
+        ddxi[m, m] += -2.0 * amp2 * h * s[m] / lam[m]
+        blk = q * w[m] * np.outer(s, s) + g * w[m] * np.diag(1.0 / lam ** 2)
+        blk[m, :] += -2.0 * g * s[m] * s / lam[m]
+        blk[:, m] += -2.0 * g * s * s[m] / lam[m]
+        blk[m, m] += -2.0 * h / lam[m] ** 3
+        dd2[m] = -amp2 * blk
+    return dk, ddxi, -ddxi, dd2
+
+
+def gradient_gp_loglike_grad(X, y, dY, kernel, lengthscale, amplitude, noise_std, grad_noise_std):
+    """What ForwardDiff yields when OptimizationMAP differentiates `data_loglike` of a GradientGaussianProcess
+    (src/model_fitters/optimization.jl:146-164 through src/models/gradient_gp.jl:367-397): the log-likelihood of the augmented
+    observation vector and its gradient w.r.t. (λ_1..λ_d, α, σ, σ_∂),
+        ∂ℓ/∂θ = ½ Σ_ab G_ab ∂K_ab/∂θ ,   G = a aᵀ − K⁻¹ ,  a = K⁻¹ỹ ,
+    over the matrix `cholesky(Symmetric(K))` factorises (upper triangle of `_build_augmented_kernel`, mirrored).  No reference test
+    covers this (PARITY UNPINNED beyond the finite differences of tests/test_oracle_crosscheck.py).
+    Returns (logpdf, grad[d + 3])."""
+    kernel = KERNEL_NAMES.get(kernel, kernel) if isinstance(kernel, str) else kernel
+    X = np.asarray(X, dtype=np.float64)
+    d, n = X.shape
+    lam = np.asarray(lengthscale, dtype=np.float64) + MIN_PARAM_VALUE
+    amp = float(amplitude) + MIN_PARAM_VALUE
+    amp2 = amp * amp
+    N = n * (1 + d)
+    post = gradient_gp_fit(X, y, dY, kernel, lengthscale, amplitude, noise_std, grad_noise_std)
+    Kinv = sla.cho_solve((post.L, True), np.eye(N), check_finite=False)
+    G = np.outer(post.alpha, post.alpha) - Kinv
+    dK = np.zeros((d + 1, N, N))                             # λ_1..λ_d, then α (noise-free part · 2/α)
+    for i in range(n):
+        for j in range(n):
+            k_val, dxi, dxj, d2 = _kernel_and_derivs(kernel, lam, amp2, X[:, i], X[:, j])
+            dk, ddxi, ddxj, dd2 = _kernel_derivs_dlam(kernel, lam, amp2, X[:, i], X[:, j])
+            dK[:d, i, j] = dk
+            dK[d, i, j] = k_val
+            for l in range(d):
+                dK[:d, i, n + l * n + j] = ddxj[:, l]
+                dK[d, i, n + l * n + j] = dxj[l]
+                dK[:d, n + l * n + i, j] = ddxi[:, l]
+                dK[d, n + l * n + i, j] = dxi[l]
+                for m in range(d):
+                    dK[:d, n + l * n + i, n + m * n + j] = dd2[:, l, m]
+                    dK[d, n + l * n + i, n + m * n + j] = d2[l, m]
+    dK[d] *= 2.0 / amp
+    grad = np.zeros(d + 3)
+    for t in range(d + 1):
+        Ks = np.triu(dK[t]) + np.triu(dK[t], 1).T            # `Symmetric(K)` reads the upper triangle
+        grad[t] = 0.5 * float(np.sum(G * Ks))
+    dg = np.diag(G)
+    grad[d + 1] = (float(noise_std) + MIN_PARAM_VALUE) * float(np.sum(dg[:n]))
+    grad[d + 2] = (float(grad_noise_std) + MIN_PARAM_VALUE) * float(np.sum(dg[n:]))
+    return post.logpdf, grad
+
+
 # ------------------------------------------------------------------------------------------
 # NonstationaryGP (SURVEY §8f4): src/models/nonstationary_gp/nonstationary_gp.jl.  λ(·), α(·), σ(·) are
 # functions of the input (posteriors of latent ParametrizedGPs, or constants, :198-212); here they arrive

@@ -1658,8 +1658,8 @@ def test_gradient_gp_errors_and_unsupported_entry_points(api, O):
     with pytest.raises(api.BossError):
         g.update([0.5, 0.5], 1.0, 0.1, -1.0)
     g.update([0.5, 0.5], 1.0, 0.1, 0.1)
-    for call in (lambda: api.GP.update(g, [0.5, 0.5], 1.0, 0.1), lambda: g.set_y(y), lambda: g.append(X[:, :1], y[:1]),
-                 lambda: g.reserve(100), lambda: g.predict_grad(X, np.zeros(n)), lambda: g.predict_cov(X), lambda: g.loglike_grad(),
+    for call in (lambda: api.GP.update(g, [0.5, 0.5], 1.0, 0.1), lambda: g.set_y(y), lambda: api.GP.append(g, X[:, :1], y[:1]),
+                 lambda: g.reserve(100), lambda: g.predict_grad(X, np.zeros(n)), lambda: g.predict_cov(X), lambda: api.GP.loglike_grad(g),
                  lambda: g.predict(X, np.zeros(n)), lambda: api.Track(g, api.Candidates(X))):
         with pytest.raises(api.BossError):
             call()
@@ -1712,6 +1712,98 @@ def test_gradient_gp_candidate_gradients(api, O, kernel, d, n, M):
     mu3, var3 = g.predict(Xs)
     assert np.all(np.abs(mu3 - mu) <= 1e-9 * (1 + np.abs(mu)))
     g.close()
+
+
+@pytest.mark.parametrize("kernel", ["matern32", "matern52", "sqexp"])
+@pytest.mark.parametrize("d,n,dup", [(1, 6, False), (3, 40, False), (2, 30, True), (8, 150, False), (16, 40, True)])
+def test_gradient_gp_likelihood_gradient(api, O, kernel, d, n, dup):
+    """SURVEY §8f3 over §8f4: ∂ℓ/∂(λ, α, σ, σ_∂) of the gradient-observation model's data_loglike (gradient_gp.jl:367-397) — what
+    ForwardDiff yields inside OptimizationMAP (src/model_fitters/optimization.jl:146-164) — against the oracle's analytic gradient
+    (itself checked against finite differences of the likelihood, tests/test_oracle_crosscheck.py); `dup` repeats a training point
+    (derivative blocks evaluated at x_j + 1e-8, gradient_gp.jl:148-152)."""
+    X, y, dY = make_grad(d, n, seed=3 * d + n)
+    if dup:
+        X[:, 1] = X[:, 0]
+    lam = np.linspace(0.35, 0.6, d)
+    hyp = (1.15, 0.04, 0.09)
+    ll_o, gr_o = O.gradient_gp_loglike_grad(X, y, dY, kernel, lam, *hyp)
+    K = O.augmented_kernel_matrix(kernel, X, lam, *hyp)
+    tol = max(1e-9, np.linalg.cond(K) * K.shape[0] * 2.0 ** -53 * 8)
+    g = api.GradGP(X, y, dY, kernel)
+    g.update(lam, *hyp)
+    ll, gr = g.loglike_grad()
+    assert gr.shape == (d + 3,)
+    assert abs(ll - ll_o) <= tol * (1 + abs(ll_o))
+    assert np.abs(gr - gr_o).max() <= tol * (1 + np.abs(gr_o).max()) * 100, (np.abs(gr - gr_o).max(), np.abs(gr_o).max())
+    ll2, gr2 = g.loglike_grad()                               # repeated on the same factorisation: bit-identical
+    assert ll2 == ll and np.array_equal(gr, gr2)
+    mu, var = g.predict(X[:, :3])                             # the handle's block inverses stay usable
+    post = O.gradient_gp_fit(X, y, dY, kernel, lam, *hyp)
+    mu_o, var_o = O.gradient_gp_mean_and_var(post, X[:, :3])
+    assert np.abs(mu - mu_o).max() <= tol * (1 + np.abs(mu_o).max()) * 10
+    g.close()
+
+
+def test_gradient_gp_append_and_gradient_map(api, O):
+    """augment_dataset! (src/types/problem.jl:191-198) on a gradient-observation handle = a fresh fit on all points at the same
+    hyper-parameters; HipGradientMAP (OptimizationMAP semantics) on a HipGradientGaussianProcess climbs its log-posterior and ends
+    where the likelihood gradient has (nearly) vanished along the free directions."""
+    import boss_jl_amd as B
+    from boss_jl_amd.gradient_gp import GradientData, HipGradientGaussianProcess, HipGradientGPParams
+    d, n = 3, 40
+    X, y, dY = make_grad(d, n + 7, seed=11)
+    lam = np.array([0.4, 0.5, 0.6])
+    g = api.GradGP(X[:, :n], y[:n], dY[:, :n], "matern52")
+    with pytest.raises(api.BossError):
+        g.append(X[:, n:], y[n:], dY[:, n:])                  # not fitted: there are no hyper-parameters to re-use
+    g.update(lam, 1.1, 0.03, 0.07)
+    lp = g.append(X[:, n:n + 1], y[n:n + 1], dY[:, n:n + 1])  # one point, then a block
+    lp = g.append(X[:, n + 1:], y[n + 1:], dY[:, n + 1:])
+    post = O.gradient_gp_fit(X, y, dY, "matern52", lam, 1.1, 0.03, 0.07)
+    assert g.n == n + 7 and g.N == (n + 7) * (1 + d)
+    assert abs(lp - post.logpdf) <= 1e-8 * (1 + abs(post.logpdf))
+    Xs = np.random.default_rng(3).uniform(0, 1, (d, 50))
+    mu, var = g.predict(Xs)
+    mu_o, var_o = O.gradient_gp_mean_and_var(post, Xs)
+    assert np.abs(mu - mu_o).max() <= 1e-8 and np.abs(var - var_o).max() <= 1e-8
+    ll, gr = g.loglike_grad()
+    _, gr_o = O.gradient_gp_loglike_grad(X, y, dY, "matern52", lam, 1.1, 0.03, 0.07)
+    assert np.abs(gr - gr_o).max() <= 1e-7 * (1 + np.abs(gr_o).max())
+    g.close()
+    # the fitter
+    P = 2
+    Y = np.stack([y, 0.5 * y + 0.1])
+    dYs = np.stack([dY, 0.5 * dY])
+    model = HipGradientGaussianProcess([B.MvLogNormal(np.full(d, -0.7), np.full(d, 0.4)) for _ in range(P)], [B.LogNormal(0.0, 0.4) for _ in range(P)],
+                                       [B.LogNormal(-3.0, 0.5) for _ in range(P)], [B.Dirac(0.07) for _ in range(P)])
+    data = GradientData(X, Y, dYs)
+    fit = B.HipGradientMAP(multistart=3, iters=12, seed=2)
+
+    class _Prob:                                              # estimate_parameters reads .model and .data only
+        pass
+    prob = _Prob()
+    prob.model, prob.data = model, data
+    from boss_jl_amd import distributed as dist_util
+    rng = np.random.default_rng(dist_util.shared_seed(2, None))
+    sampler = model.params_sampler()
+    starts = [sampler(rng) for _ in range(3)]
+    prior_ll = model.params_loglike()
+    llg = model.data_loglike_grad(data)
+    f0 = [llg(p)[0] + prior_ll(p) for p in starts]
+    for h in llg.handles:
+        h.close()
+    res = fit.estimate_parameters(prob, return_all=True)
+    assert len(res) == 3
+    for r, f_start, p0 in zip(res, f0, starts):
+        assert r.loglike >= f_start - 1e-9                    # never below its start
+        assert np.array_equal(r.params.grad_noise_std, p0.grad_noise_std)   # Dirac prior: fixed (dirac.jl:36-77)
+    assert max(r.loglike for r in res) > max(f0) + 1.0        # and the climb is real
+    best = fit.estimate_parameters(prob)
+    assert best.loglike == max(r.loglike for r in res)
+    # oracle value of the winner's log-likelihood
+    want = sum(O.gradient_gp_fit(X, Y[i], dYs[i], "matern52", best.params.lengthscales[:, i], best.params.amplitudes[i],
+                                 best.params.noise_std[i], best.params.grad_noise_std[i]).logpdf for i in range(P)) + prior_ll(best.params)
+    assert abs(best.loglike - want) <= 1e-7 * (1 + abs(want))
 
 
 def test_gradient_gp_acquisition_and_host_mirror(api, O):

@@ -366,3 +366,27 @@ def test_nonstationary_candidate_gradients_match_finite_differences():
         (mp, vp), (mm, vm) = f(Zp), f(Zm)
         assert np.abs((mp - mm) / (2 * e) - dmu[m]).max() <= 1e-6 * (1 + np.abs(dmu[m]).max())
         assert np.abs((vp - vm) / (2 * e) - dvar[m]).max() <= 1e-6 * (1 + np.abs(dvar[m]).max())
+
+
+@pytest.mark.parametrize("kernel", [O.MATERN32, O.MATERN52, O.SQEXP])
+def test_gradient_gp_likelihood_gradient_matches_finite_differences(kernel):
+    """oracle.gradient_gp_loglike_grad (∂ℓ/∂(λ, α, σ, σ_∂) of the gradient-observation model, incl. the third radial profile and the
+    upper-triangle convention of `Symmetric(K)`) against central differences of gradient_gp_fit(...).logpdf — also with a repeated
+    training point, whose derivative blocks the reference evaluates at x_j + 1e-8 (gradient_gp.jl:148-152)."""
+    rng = np.random.default_rng(7)
+    for d, n, dup in ((1, 5, False), (3, 9, False), (2, 8, True)):
+        X = rng.uniform(0, 1, (d, n))
+        if dup:
+            X[:, 1] = X[:, 0]
+        y = np.sin(3 * X).sum(0)
+        dY = 3 * np.cos(3 * X)
+        th = np.concatenate([rng.uniform(0.4, 0.8, d), [1.2, 0.05, 0.08]])
+        f = lambda t: O.gradient_gp_fit(X, y, dY, kernel, t[:d], t[d], t[d + 1], t[d + 2]).logpdf
+        ll, g = O.gradient_gp_loglike_grad(X, y, dY, kernel, th[:d], th[d], th[d + 1], th[d + 2])
+        assert ll == f(th)
+        fd = np.zeros(d + 3)
+        for i in range(d + 3):
+            e = np.zeros(d + 3)
+            e[i] = 1e-6 * max(1.0, abs(th[i]))
+            fd[i] = (f(th + e) - f(th - e)) / (2 * e[i])
+        assert np.abs(g - fd).max() <= 2e-6 * (1 + np.abs(fd).max()), (kernel, d, n, dup, g, fd)
