@@ -39,6 +39,7 @@ SIGNATURES = {
     "boss_ngp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_ggp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_void_p)]),
     "boss_ggp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, C.c_double, C.c_int, _c_dp]),
+    "boss_ngp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_ggp_loglike_grad": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
     "boss_ggp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_gp_fit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, C.c_double, C.c_double,
@@ -476,6 +477,24 @@ class GibbsGP(GP):
             self.logpdf = out.value
             return out.value
         return None
+
+    def append(self, X_new, y_new, lam_new, amp_new, noise_new, mean_new=None) -> float:
+        """augment_dataset! + the posterior with the latent models evaluated at the new points (lam_new d×m, amp_new m, noise_new m):
+        rebuilt and factorised (boss_ngp_append).  Returns the logpdf of all N + m points."""
+        X_new = _f64(np.asarray(X_new, dtype=np.float64).reshape(self.d, -1), 2)
+        m = X_new.shape[1]
+        y_new = _f64(np.asarray(y_new).reshape(-1), 1)
+        lam = _f64(np.asarray(lam_new, dtype=np.float64).reshape(self.d, -1), 2)
+        amp = _f64(np.asarray(amp_new).reshape(-1), 1)
+        noi = _f64(np.asarray(noise_new).reshape(-1), 1)
+        mn = None if mean_new is None else _f64(np.asarray(mean_new).reshape(-1), 1)
+        if y_new.shape[0] != m or lam.shape != (self.d, m) or amp.shape[0] != m or noi.shape[0] != m or (mn is not None and mn.shape[0] != m):
+            raise ValueError("one entry (column) per new point in y_new, lam_new, amp_new, noise_new, mean_new")
+        out = C.c_double(0.0)
+        _check(load_library().boss_ngp_append(self._h, m, _dp(X_new), _dp(y_new), _dp(lam), _dp(amp), _dp(noi), _dp(mn), C.byref(out)))
+        self.N += m
+        self.logpdf = out.value
+        return out.value
 
     def predict(self, Xs, lam_Xs, amp_Xs, mean_Xs=None):
         """mean_and_var with _clip_var; lam_Xs d×M and amp_Xs M are λ(x*), α(x*)."""

@@ -729,7 +729,7 @@ end
 # ---------------------------------------------------------------- NonstationaryGP (Gibbs kernel)
 # The latent models stay BOSS's own (ParametrizedGP posteriors or constants); only their values cross the ABI.
 struct HipNonstationaryPosterior <: BOSS.ModelPosteriorSlice{BOSS.NonstationaryGP}
-    post::HipPosteriorSlice; f_λ; f_α; discrete
+    post::HipPosteriorSlice; f_λ; f_α; discrete; f_σ
 end
 rounded(X, ::Nothing) = X
 rounded(X, disc) = (Xr = copy(X); Xr[disc, :] .= round.(Xr[disc, :]); Xr)
@@ -744,7 +744,16 @@ function hip_posterior_slice(model::BOSS.NonstationaryGP, params::BOSS.Nonstatio
           device, size(X, 1), size(X, 2), X, Vector{Float64}(data.Y[i, :]), isnothing(model.discrete) ? C_NULL : UInt8.(model.discrete), h))
     check(ccall((:boss_ngp_update, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ref{Cdouble}),
           h[], reduce(hcat, f_λ.(eachcol(Xr))), Float64.(f_α.(eachcol(Xr))), Float64.(f_σ.(eachcol(X))), mean_vals(mu, X), 0, lp))
-    return HipNonstationaryPosterior(HipPosteriorSlice(Handle(h[]), mu), f_λ, f_α, model.discrete), lp[]   # lp = data_loglike_slice
+    return HipNonstationaryPosterior(HipPosteriorSlice(Handle(h[]), mu), f_λ, f_α, model.discrete, f_σ), lp[]   # lp = data_loglike_slice
+end
+"augment_dataset! (src/types/problem.jl:191-198) for a fitted nonstationary slice: the latent models are evaluated at the new points only."
+function augment!(p::HipNonstationaryPosterior, X_new::AbstractMatrix{<:Real}, y_new::AbstractVector{<:Real})
+    Xn = Matrix{Float64}(X_new); Xr = rounded(Xn, p.discrete); lp = Ref{Cdouble}()
+    GC.@preserve p check(ccall((:boss_ngp_append, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
+        p.post.h.h, size(Xn, 2), Xn, Vector{Float64}(y_new), reduce(hcat, p.f_λ.(eachcol(Xr))), Float64.(p.f_α.(eachcol(Xr))),
+        Float64.(p.f_σ.(eachcol(Xn))), mean_vals(p.post.mean, Xn), lp))
+    return lp[]
 end
 function mean_and_var(p::HipNonstationaryPosterior, X::AbstractMatrix{<:Real})
     Xs = Matrix{Float64}(X); Xr = rounded(Xs, p.discrete); M = size(Xs, 2)

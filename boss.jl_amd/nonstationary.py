@@ -132,6 +132,18 @@ class HipNonstationaryPosteriorSlice:
     f_amp: Callable
     mean_fn: Optional[Callable]
     discrete: Optional[np.ndarray]
+    f_noise: Optional[Callable] = None                          # σ(·): needed by append only
+
+    def append(self, x, y) -> float:
+        """augment_dataset! (src/types/problem.jl:191-198) on the fitted slice: the latent models are evaluated at the new points, the
+        system is rebuilt and factorised (boss_ngp_append).  x: d×m (or length d), y: m.  Returns the logpdf of all points."""
+        if self.f_noise is None:
+            raise ValueError("this slice was built without its noise model")
+        X = np.asarray(x, float).reshape(self.gp.d, -1)
+        Xr = self._round(X)
+        ms = None if self.mean_fn is None else np.array([float(self.mean_fn(X[:, j])) for j in range(X.shape[1])])
+        return self.gp.append(X, np.asarray(y, float).reshape(-1), _cols(self.f_lam, Xr).T, _cols(self.f_amp, Xr).reshape(-1),
+                              _cols(self.f_noise, X).reshape(-1), ms)
 
     def _round(self, X):
         if self.discrete is None:
@@ -216,7 +228,7 @@ class HipNonstationaryGP:
         except Exception:
             g.close()
             raise
-        return HipNonstationaryPosteriorSlice(g, self.f_lam[i], self.f_amp[i], None if self.mean is None else self.mean[i], disc)
+        return HipNonstationaryPosteriorSlice(g, self.f_lam[i], self.f_amp[i], None if self.mean is None else self.mean[i], disc, self.f_noise[i])
 
     def model_posterior(self, data: ExperimentData) -> List[HipNonstationaryPosteriorSlice]:
         return [self.model_posterior_slice(data, i) for i in range(data.Y.shape[0])]

@@ -186,6 +186,12 @@ int boss_ngp_create(int device, int d, int N, const double* X, const double* y, 
                     boss_gp_t** out);
 int boss_ngp_update(boss_gp_t* gp, const double* lam_X, const double* amp_X, const double* noise_X,
                     const double* mean_X, int flags, double* logpdf_out);
+/* augment_dataset! (src/types/problem.jl:191-198) for a fitted nonstationary posterior: n_new further observations with the latent
+ * models' values AT THE NEW POINTS (lam_new d×n_new, amp_new, noise_new; mean_new when the posterior has a prior mean); the values
+ * at the old points are the resident ones.  Every kernel entry couples both points' lengthscales, so — as in the reference — the
+ * system is rebuilt and factorised; the handle stays the same object.  Needs a fitted handle (BOSS_E_NOT_FITTED otherwise). */
+int boss_ngp_append(boss_gp_t* gp, int n_new, const double* X_new, const double* y_new, const double* lam_new,
+                    const double* amp_new, const double* noise_new, const double* mean_new, double* logpdf_out);
 int boss_ngp_predict(boss_gp_t* gp, int M, const double* Xs, const double* lam_Xs, const double* amp_Xs,
                      const double* mean_Xs, double* mu, double* var, long* bad_index);
 /* mean_and_var of a nonstationary posterior AND its gradient w.r.t. the candidates.

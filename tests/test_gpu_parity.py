@@ -1928,6 +1928,49 @@ def test_nonstationary_gp_parity(api, O, d, N, M):
     g.close()
 
 
+@pytest.mark.parametrize("disc", [False, True])
+def test_nonstationary_gp_append(api, O, disc):
+    """augment_dataset! (src/types/problem.jl:191-198) on a nonstationary posterior = a fresh fit on all points with the latent models
+    evaluated at the new ones (boss_ngp_append through the C ABI and through the host mirror), prior mean and discrete dimensions
+    included; refused before the first update."""
+    from boss_jl_amd.nonstationary import HipNonstationaryGP
+    from boss_jl_amd.problem import ExperimentData
+    d, N, n_new = 3, 150, 9
+    X, y, Xs = make(d, N + n_new, 40, seed=21)
+    discrete = np.array([False, True, False]) if disc else None
+    if disc:
+        X[1] *= 5
+        Xs[1] *= 5
+    f_lam, f_amp, f_noise = latent(d)
+    rnd = lambda Z: Z if discrete is None else np.where(discrete[:, None], np.rint(Z), Z)   # noqa: E731
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                   # noqa: E731
+    lamX, ampX, noiX = ev(f_lam, rnd(X)).T, ev(f_amp, rnd(X)), ev(f_noise, X)
+    mfun = lambda Z: 0.3 * Z[0]                                                           # noqa: E731
+    g = api.GibbsGP(X[:, :N], y[:N], discrete)
+    with pytest.raises(api.BossError):
+        g.append(X[:, N:], y[N:], lamX[:, N:], ampX[N:], noiX[N:], mfun(X[:, N:]))
+    g.update(lamX[:, :N], ampX[:N], noiX[:N], mfun(X[:, :N]))
+    with pytest.raises(api.BossError):
+        g.append(X[:, N:], y[N:], lamX[:, N:], ampX[N:], noiX[N:])                        # the posterior has a prior mean
+    lp = g.append(X[:, N:N + 1], y[N:N + 1], lamX[:, N:N + 1], ampX[N:N + 1], noiX[N:N + 1], mfun(X[:, N:N + 1]))
+    lp = g.append(X[:, N + 1:], y[N + 1:], lamX[:, N + 1:], ampX[N + 1:], noiX[N + 1:], mfun(X[:, N + 1:]))
+    post = O.nonstationary_fit(X, y, lamX, ampX, noiX, mean=mfun(X), discrete=discrete)
+    assert g.N == N + n_new and abs(lp - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf))
+    lamS, ampS = ev(f_lam, rnd(Xs)).T, ev(f_amp, rnd(Xs))
+    mu, var = g.predict(Xs, lamS, ampS, mfun(Xs))
+    mu_o, var_o = O.nonstationary_mean_and_var(post, Xs, lamS, ampS, mean_s=mfun(Xs))
+    assert np.abs(mu - mu_o).max() <= 1e-9 and np.abs(var - var_o).max() <= 1e-9
+    g.close()
+    # the host mirror evaluates the latent models itself
+    model = HipNonstationaryGP([f_lam], [f_amp], [f_noise], [lambda x: 0.3 * x[0]], None if discrete is None else list(discrete))
+    sl = model.model_posterior_slice(ExperimentData(X[:, :N], y[None, :N]), 0)
+    lp_h = sl.append(X[:, N:], y[N:])
+    assert abs(lp_h - post.logpdf) <= 1e-9 * (1 + abs(post.logpdf))
+    mu_h, var_h = sl.mean_and_var(Xs)
+    assert np.abs(mu_h - mu_o).max() <= 1e-9 and np.abs(var_h - var_o).max() <= 1e-9
+    sl.close()
+
+
 @pytest.mark.parametrize("d,N,M", [(1, 20, 5), (3, 300, 70), (8, 1100, 40), (16, 150, 33)])
 def test_nonstationary_gp_candidate_gradients(api, O, d, N, M):
     """SURVEY §8f3 over §8f4: ∇μ, ∇σ² of a nonstationary posterior — the candidate enters the Gibbs kernel directly and through
@@ -2029,7 +2072,7 @@ def test_nonstationary_gp_discrete_errors_and_host_mirror(api, O):
     want = O.expected_improvement_lin([1.0, 0.0], mu, var, 0.5) * O.feas_prob(mu, var, [np.inf, 1.0])
     assert np.allclose(acq, want, rtol=0, atol=1e-12) and am == int(np.argmax(want))
     g = posts[0].gp
-    for call in (lambda: api.GP.update(g, [1.0, 1.0], 1.0, 0.1), lambda: api.GP.predict(g, Xs), lambda: g.append(X[:, :1], [0.0]),
+    for call in (lambda: api.GP.update(g, [1.0, 1.0], 1.0, 0.1), lambda: api.GP.predict(g, Xs), lambda: api.GP.append(g, X[:, :1], [0.0]),
                  lambda: api.GP.predict_grad(g, Xs), lambda: g.predict_cov(Xs), lambda: g.loglike_grad(),
                  lambda: api.acq_ei([[g]], api.Candidates(Xs), [1.0], None, 0.0, None),
                  lambda: g.update(np.zeros((d, N)), np.ones(N), np.ones(N)),             # λ = 0
