@@ -3,8 +3,8 @@
 #   1. kernel trace + stats of the default bench command           -> profiles/<tag>_bench_kernel_stats.csv
 #   2. separate --pmc passes for FETCH_SIZE, WRITE_SIZE and the MFMA-pipe counters -> profiles/<tag>_pmc_summary.json (carries the source hash)
 #   3. the bench line itself (no profiler)                           -> profiles/<tag>_bench.json
-#   4. device timeline of one N=4096 update under the resident chain -> profiles/<tag>_chain_timeline.log (needs tools/libbosship_t3.so:
-#      python tools/chain_trace3.py --build on the CPU box first)
+#   4. device timeline of one N=4096 update under the resident chain -> profiles/<tag>_chain_timeline.log (the traced build of the same
+#      sources, -DBOSS_CHAIN_TRACE, is compiled here into /tmp: nothing but the shipped library travels in the tree)
 # usage: bash tools/collect_profiles.sh r03_v1
 set -e
 tag=${1:-r03}
@@ -19,9 +19,15 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -o w
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_m -o m -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --with-config5 > $out/bench_m.json 2> $out/m.err || true
 python3 tools/pmc_summary.py $(find $out/pmc_f -name "f_counter_collection.csv" | head -1) $(find $out/pmc_w -name "w_counter_collection.csv" | head -1) profiles/${tag}_pmc_summary.json $(find $out/pmc_m -name "m_counter_collection.csv" | head -1)
 python3 bench.py --steps 50 --warmup 5 > profiles/${tag}_bench.json 2> $out/bench.err
-if [ -f tools/libbosship_t3.so ]; then python3 tools/chain_trace3.py 4096 > profiles/${tag}_chain_timeline.log 2> $out/trace.err || true; fi
+export BOSS_TRACE_LIB=/tmp/libbosship_t3_$tag.so
+python3 tools/chain_trace3.py --build > $out/trace_build.log 2>&1 || true
+if [ -f $BOSS_TRACE_LIB ]; then
+    python3 tools/chain_trace3.py 4096 > profiles/${tag}_chain_timeline.log 2> $out/trace.err || true
+    python3 tools/rider_timeline.py > profiles/${tag}_rider_timeline.log 2> $out/rider_trace.err || true
+    M=2048 python3 tools/rider_timeline.py > profiles/${tag}_rider_timeline_M2048.log 2>> $out/rider_trace.err || true
+fi
 echo "profiles written for $tag"
-if [ -f tools/libbosship_t3.so ]; then python3 tools/rider_timeline.py > profiles/${tag}_rider_timeline.log 2> $out/rider_trace.err || true; fi
+python3 tools/rider_probe.py > profiles/${tag}_rider_probe.log 2> $out/rider_probe.err || true
 python3 tools/rider_time.py > profiles/${tag}_rider_time.log 2> $out/rider_time.err || true
 python3 tools/stall_hunt.py > profiles/${tag}_update_latency_2000.log 2> $out/stall.err || true
 # 300 back-to-back updates under the kernel trace: chain-kernel durations and main-stream gaps inside every update

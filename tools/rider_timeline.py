@@ -5,7 +5,7 @@ accumulate end."""
 import os, sys, subprocess, ctypes as C, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "libbosship_t3.so")
+LIB = os.environ.get("BOSS_TRACE_LIB", os.path.join(ROOT, "tools", "libbosship_t3.so"))
 
 
 def build():
