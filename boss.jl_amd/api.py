@@ -39,6 +39,7 @@ SIGNATURES = {
     "boss_ngp_predict": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_long)]),
     "boss_ggp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, C.POINTER(C.c_void_p)]),
     "boss_ggp_update": (C.c_int, [C.c_void_p, _c_dp, C.c_double, C.c_double, C.c_double, C.c_int, _c_dp]),
+    "boss_ngp_loglike_grad": (C.c_int, [C.c_void_p, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_ngp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "boss_ggp_loglike_grad": (C.c_int, [C.c_void_p, _c_dp, _c_dp]),
     "boss_ggp_append": (C.c_int, [C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
@@ -477,6 +478,15 @@ class GibbsGP(GP):
             self.logpdf = out.value
             return out.value
         return None
+
+    def loglike_grad(self):
+        """(logpdf, dlam[d, N], damp[N], dnoise[N], dmean[N]): the log-likelihood of the last update and its partial derivatives w.r.t.
+        the latent models' values at the training points (boss_ngp_loglike_grad)."""
+        out = C.c_double(0.0)
+        dlam = np.zeros((self.d, self.N), order="F")
+        damp, dnoi, dmean = np.zeros(self.N), np.zeros(self.N), np.zeros(self.N)
+        _check(load_library().boss_ngp_loglike_grad(self._h, C.byref(out), _dp(dlam), _dp(damp), _dp(dnoi), _dp(dmean)))
+        return out.value, dlam, damp, dnoi, dmean
 
     def append(self, X_new, y_new, lam_new, amp_new, noise_new, mean_new=None) -> float:
         """augment_dataset! + the posterior with the latent models evaluated at the new points (lam_new d×m, amp_new m, noise_new m):

@@ -834,6 +834,109 @@ __global__ __launch_bounds__(256) void llgrad_reduce_kernel(const double* __rest
     if (threadIdx.x == 0) out[m] = red[0];
 }
 
+// ------------------------------------------------------------------------------------------
+// Likelihood gradient of the nonstationary model w.r.t. the latent models' values at the training points (boss_ngp_loglike_grad):
+//   ∂ℓ/∂λ_il = Σ_j G_ij K⁰_ij [½ (1/λ_il − 2 λ_il/q_l) + 2 λ_il Δ_l²/q_l²] ,  ∂ℓ/∂α_i = Σ_j G_ij K⁰_ij 2/(α_i + α_j) ,
+//   ∂ℓ/∂σ_i = σ_i G_ii ,  ∂ℓ/∂m_i = a_i ,     G = a aᵀ − K⁻¹,  q_l = λ_il² + λ_jl²,  Δ_l = x_il − x_jl.
+// K⁻¹ arrives with its lower triangle valid (kinv_syrk_kernel); mirror_lower_kernel fills the upper one so that row i of the
+// symmetric matrix is read as column i (coalesced over the 64 rows of a workgroup).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int ld, int Np) {
+    __shared__ double t[64][65];
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj >= bi) return;                                    // (strictly lower tiles are copied into their mirror images; diagonal tiles: below)
+    const int r = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    for (int c = cg; c < 64; c += 4) t[c][r] = A[(size_t)(bj * 64 + c) * ld + bi * 64 + r];   // element (row bi·64 + r, column bj·64 + c)
+    __syncthreads();
+    for (int c = cg; c < 64; c += 4) A[(size_t)(bi * 64 + c) * ld + bj * 64 + r] = t[r][c];   // element (row bj·64 + r, column bi·64 + c) = (bi·64 + c, bj·64 + r)
+}
+__global__ __launch_bounds__(256) void mirror_diag_kernel(double* __restrict__ A, int ld) {
+    const int b = blockIdx.x, r = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    for (int c = cg; c < 64; c += 4)
+        if (c > r) A[(size_t)(b * 64 + c) * ld + b * 64 + r] = A[(size_t)(b * 64 + r) * ld + b * 64 + c];
+}
+// grid (Np/64, JS): rows bi·64 .. +63, columns of split js; thread (r, cg) takes the columns j ≡ cg (mod 4) of the split.
+// part[(js·4 + cg)][v][Np]: v = 0..d-1 the λ sums, d the α sum.
+__global__ __launch_bounds__(256) void gibbs_llgrad_kernel(const double* __restrict__ X, const double* __restrict__ Lam,
+                                                           const double* __restrict__ amp, int d, int N, int Np,
+                                                           const double* __restrict__ Kinv, int ldk, const double* __restrict__ apart,
+                                                           int nch, double* __restrict__ part) {
+    constexpr int DM = GIBBS_GRAD_MAX_D;
+    __shared__ double xj[DM][64], lj[DM][64], aj[64], mj[64];
+    const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+    const int i = blockIdx.x * 64 + r, js = blockIdx.y, JS = gridDim.y;
+    const int ntile = Np / 64, t0 = (int)((long long)ntile * js / JS), t1 = (int)((long long)ntile * (js + 1) / JS);
+    double xi[DM], li[DM], S[DM + 1];
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+        xi[k] = k < d ? X[(size_t)k * Np + i] : 0.0;
+        li[k] = k < d ? Lam[(size_t)k * Np + i] : 1.0;
+        S[k] = 0.0;
+    }
+    S[DM] = 0.0;
+    double ai = 0.0;
+    for (int c = 0; c < nch; ++c) ai += apart[(size_t)c * Np + i];
+    const double ami = amp[i];
+    for (int tj = t0; tj < t1; ++tj) {
+        __syncthreads();
+        for (int idx = tid; idx < d * 64; idx += 256) {
+            xj[idx >> 6][idx & 63] = X[(size_t)(idx >> 6) * Np + tj * 64 + (idx & 63)];
+            lj[idx >> 6][idx & 63] = Lam[(size_t)(idx >> 6) * Np + tj * 64 + (idx & 63)];
+        }
+        if (tid < 64) {
+            double s = 0.0;
+            for (int c = 0; c < nch; ++c) s += apart[(size_t)c * Np + tj * 64 + tid];
+            aj[tid] = s;
+            mj[tid] = amp[tj * 64 + tid];
+        }
+        __syncthreads();
+        for (int c = cg; c < 64; c += 4) {
+            const int j = tj * 64 + c;
+            if (i >= N || j >= N) continue;
+            double pr = 1.0, es = 0.0, D[DM];
+#pragma unroll
+            for (int k = 0; k < DM; ++k) {
+                if (k < d) {
+                    const double lx = li[k], ly = lj[k][c];
+                    const double q = rcp_refined(__builtin_fma(lx, lx, ly * ly));
+                    const double df = xi[k] - xj[k][c];
+                    pr *= 2.0 * lx * ly * q;
+                    es = __builtin_fma(df * df, q, es);
+                    D[k] = 0.5 * (1.0 / lx - 2.0 * lx * q) + 2.0 * lx * df * df * q * q;
+                } else {
+                    D[k] = 0.0;
+                }
+            }
+            const double am = 0.5 * (ami + mj[c]);
+            const double w = (ai * aj[c] - Kinv[(size_t)j * ldk + i]) * am * am * sqrt(pr) * exp(-es);
+#pragma unroll
+            for (int k = 0; k < DM; ++k) S[k] = __builtin_fma(w, D[k], S[k]);
+            S[DM] = __builtin_fma(w, 1.0 / am, S[DM]);               // 2/(α_i + α_j)
+        }
+    }
+    double* P = part + (size_t)(js * 4 + cg) * (d + 1) * Np;
+#pragma unroll
+    for (int k = 0; k < DM; ++k)
+        if (k < d) P[(size_t)k * Np + i] = S[k];
+    P[(size_t)d * Np + i] = S[DM];
+}
+// out: dlam [d][Np] | damp [Np] | dnoise [Np] | dmean [Np], the parts summed in slot order
+__global__ __launch_bounds__(256) void gibbs_llgrad_reduce_kernel(const double* __restrict__ part, int nparts, int d, int N, int Np,
+                                                                  const double* __restrict__ noise, const double* __restrict__ Kinv, int ldk,
+                                                                  const double* __restrict__ apart, int nch, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    for (int v = 0; v <= d; ++v) {
+        double s = 0.0;
+        for (int p = 0; p < nparts; ++p) s += part[((size_t)p * (d + 1) + v) * Np + i];
+        out[(size_t)v * Np + i] = i < N ? s : 0.0;
+    }
+    double ai = 0.0;
+    for (int c = 0; c < nch; ++c) ai += apart[(size_t)c * Np + i];
+    out[(size_t)(d + 1) * Np + i] = i < N ? noise[i] * (ai * ai - Kinv[(size_t)i * ldk + i]) : 0.0;
+    out[(size_t)(d + 2) * Np + i] = i < N ? ai : 0.0;
+}
+
 __global__ __launch_bounds__(32) void grad_finalize_kernel(const double* __restrict__ part, int rsplit,
                                                            const double* __restrict__ Csc, int d, int Mp, int M,
                                                            const double* __restrict__ invlam,

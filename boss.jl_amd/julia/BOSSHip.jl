@@ -746,6 +746,18 @@ function hip_posterior_slice(model::BOSS.NonstationaryGP, params::BOSS.Nonstatio
           h[], reduce(hcat, f_λ.(eachcol(Xr))), Float64.(f_α.(eachcol(Xr))), Float64.(f_σ.(eachcol(X))), mean_vals(mu, X), 0, lp))
     return HipNonstationaryPosterior(HipPosteriorSlice(Handle(h[]), mu), f_λ, f_α, model.discrete, f_σ), lp[]   # lp = data_loglike_slice
 end
+"""
+Log-likelihood of a fitted nonstationary slice with its partial derivatives w.r.t. the latent models' values at the training points:
+(ℓ, ∂ℓ/∂λ(x_j) (x_dim × N), ∂ℓ/∂α(x_j), ∂ℓ/∂σ(x_j), ∂ℓ/∂m(x_j)) — the cotangents a reverse rule for `data_loglike_slice`
+(nonstationary_gp.jl:237-245) hands to the latent `ParametrizedGP` posteriors; with ForwardDiff duals in the latent parameters the
+directional derivative is their dot product with the duals' partials.
+"""
+function loglike_grad_values(p::HipNonstationaryPosterior, N::Int, d::Int)
+    lp = Ref{Cdouble}(); dλ = Matrix{Float64}(undef, d, N); dα = Vector{Float64}(undef, N); dσ = similar(dα); dm = similar(dα)
+    GC.@preserve p check(ccall((:boss_ngp_loglike_grad, lib), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        p.post.h.h, lp, dλ, dα, dσ, dm))
+    return lp[], dλ, dα, dσ, dm
+end
 "augment_dataset! (src/types/problem.jl:191-198) for a fitted nonstationary slice: the latent models are evaluated at the new points only."
 function augment!(p::HipNonstationaryPosterior, X_new::AbstractMatrix{<:Real}, y_new::AbstractVector{<:Real})
     Xn = Matrix{Float64}(X_new); Xr = rounded(Xn, p.discrete); lp = Ref{Cdouble}()

@@ -145,6 +145,12 @@ class HipNonstationaryPosteriorSlice:
         return self.gp.append(X, np.asarray(y, float).reshape(-1), _cols(self.f_lam, Xr).T, _cols(self.f_amp, Xr).reshape(-1),
                               _cols(self.f_noise, X).reshape(-1), ms)
 
+    def loglike_grad(self):
+        """(logpdf, dlam[d, N], damp[N], dnoise[N], dmean[N]): data_loglike_slice (nonstationary_gp.jl:237-245) of the fitted slice and
+        its partial derivatives w.r.t. the latent models' values at the training points (boss_ngp_loglike_grad) — the cotangents a
+        gradient-based fitter chains through its latent models."""
+        return self.gp.loglike_grad()
+
     def _round(self, X):
         if self.discrete is None:
             return X

@@ -192,6 +192,13 @@ int boss_ngp_update(boss_gp_t* gp, const double* lam_X, const double* amp_X, con
  * system is rebuilt and factorised; the handle stays the same object.  Needs a fitted handle (BOSS_E_NOT_FITTED otherwise). */
 int boss_ngp_append(boss_gp_t* gp, int n_new, const double* X_new, const double* y_new, const double* lam_new,
                     const double* amp_new, const double* noise_new, const double* mean_new, double* logpdf_out);
+/* data_loglike_slice (nonstationary_gp.jl:237-245) with its partial derivatives w.r.t. the latent models' VALUES at the training
+ * points — what a gradient-based fitter's AD carries back to the latent models through finite_nongp (:183-196); the caller chains
+ * them through its own latent models.  At the parameters of the last boss_ngp_update; every output may be NULL:
+ *   dlam_out d×N (column j = d logpdf / d l(x_j), the layout of lam_X), damp_out N, dnoise_out N, dmean_out N (= K^-1 (y - m)).
+ * x_dim <= 16. */
+int boss_ngp_loglike_grad(boss_gp_t* gp, double* logpdf_out, double* dlam_out, double* damp_out, double* dnoise_out,
+                          double* dmean_out);
 int boss_ngp_predict(boss_gp_t* gp, int M, const double* Xs, const double* lam_Xs, const double* amp_Xs,
                      const double* mean_Xs, double* mu, double* var, long* bad_index);
 /* mean_and_var of a nonstationary posterior AND its gradient w.r.t. the candidates.

@@ -957,6 +957,36 @@ def nonstationary_fit(X, y, lam_X, amp_X, noise_X, mean=None, discrete=None) -> 
                                   None if discrete is None else np.asarray(discrete, bool), L, a, logpdf)
 
 
+def nonstationary_loglike_grad(X, y, lam_X, amp_X, noise_X, mean=None, discrete=None):
+    """What ForwardDiff carries back to the latent models when a fitter differentiates `data_loglike_slice` of a NonstationaryGP
+    (nonstationary_gp.jl:237-245 through finite_nongp :183-196): the log-likelihood and its partial derivatives w.r.t. the latent
+    models' VALUES at the training points — λ(x_i) (d×N), α(x_i), σ(x_i), m(x_i); the caller chains them through its latent models.
+    With G = a aᵀ − K⁻¹, a = K⁻¹(y − m), K⁰ the noise-free Gibbs Gram matrix, q_l = λ_il² + λ_jl², Δ_l = x_il − x_jl:
+        ∂ℓ/∂λ_il = Σ_j G_ij K⁰_ij [½ (1/λ_il − 2 λ_il/q_l) + 2 λ_il Δ_l²/q_l²] ,   ∂ℓ/∂α_i = Σ_j G_ij K⁰_ij 2/(α_i + α_j) ,
+        ∂ℓ/∂σ_i = σ_i G_ii ,   ∂ℓ/∂m_i = a_i
+    (the j = i terms: the bracket vanishes, and K⁰_ii 2/(2α_i) = α_i is ½ ∂K_ii/∂α_i).  No reference test covers this (PARITY
+    UNPINNED beyond the finite differences of tests/test_oracle_crosscheck.py).  Returns (logpdf, dlam[d, N], damp[N], dnoise[N], dmean[N])."""
+    X = np.asarray(X, dtype=np.float64)
+    lam = np.asarray(lam_X, dtype=np.float64)
+    amp = np.asarray(amp_X, dtype=np.float64).reshape(-1)
+    noi = np.asarray(noise_X, dtype=np.float64).reshape(-1)
+    d, N = X.shape
+    post = nonstationary_fit(X, y, lam, amp, noi, mean=mean, discrete=discrete)
+    Xr = discrete_round(X, discrete)
+    K0 = gibbs_kernel_matrix(Xr, lam, amp, Xr, lam, amp)
+    Kinv = sla.cho_solve((post.L, True), np.eye(N), check_finite=False)
+    W = (np.outer(post.a, post.a) - Kinv) * K0
+    dlam = np.zeros((d, N))
+    for l in range(d):
+        q = lam[l][:, None] ** 2 + lam[l][None, :] ** 2
+        dl2 = (Xr[l][:, None] - Xr[l][None, :]) ** 2
+        D = 0.5 * (1.0 / lam[l][:, None] - 2.0 * lam[l][:, None] / q) + 2.0 * lam[l][:, None] * dl2 / q ** 2
+        dlam[l] = np.sum(W * D, axis=1)
+    damp = np.sum(W * (2.0 / (amp[:, None] + amp[None, :])), axis=1)
+    dnoise = noi * (post.a ** 2 - np.diag(Kinv))
+    return post.logpdf, dlam, damp, dnoise, post.a.copy()
+
+
 def nonstationary_mean_and_var(post: NonstationaryPosterior, Xs, lam_Xs, amp_Xs, mean_s=None, clip: bool = True):
     """mean_and_var of the GaussianProcessPosterior built over the NonstationaryKernel (gaussian_process.jl:174-178):
     k(x*,x*) = α(x*)², + 1e-18, then _clip_var."""

@@ -1928,6 +1928,42 @@ def test_nonstationary_gp_parity(api, O, d, N, M):
     g.close()
 
 
+@pytest.mark.parametrize("d,N,disc", [(1, 5, False), (3, 150, True), (8, 700, False), (16, 1100, False)])
+def test_nonstationary_gp_likelihood_gradient(api, O, d, N, disc):
+    """∂ℓ/∂ of the latent values at the training points (boss_ngp_loglike_grad) — what a fitter's AD hands back to the latent
+    models through finite_nongp (nonstationary_gp.jl:183-196, 237-245) — against the oracle (finite-difference checked,
+    tests/test_oracle_crosscheck.py); prior mean and a rounded dimension included."""
+    X, y, _ = make(d, N, 4, seed=31)
+    discrete = None
+    if disc:
+        discrete = np.zeros(d, bool)
+        discrete[1] = True
+        X[1] *= 5
+    f_lam, f_amp, f_noise = latent(d)
+    rnd = lambda Z: Z if discrete is None else np.where(discrete[:, None], np.rint(Z), Z)   # noqa: E731
+    ev = lambda f, Z: np.array([f(Z[:, j]) for j in range(Z.shape[1])])                   # noqa: E731
+    lamX, ampX, noiX = ev(f_lam, rnd(X)).T, ev(f_amp, rnd(X)), ev(f_noise, X)
+    mX = 0.3 * X[0]
+    ll_o, dl_o, da_o, dn_o, dm_o = O.nonstationary_loglike_grad(X, y, lamX, ampX, noiX, mean=mX, discrete=discrete)
+    post = O.nonstationary_fit(X, y, lamX, ampX, noiX, mean=mX, discrete=discrete)
+    tol = max(1e-9, np.linalg.cond(post.L @ post.L.T) * N * 2.0 ** -53 * 8)
+    g = api.GibbsGP(X, y, discrete)
+    with pytest.raises(api.BossError):
+        g.loglike_grad()                                      # not fitted
+    g.update(lamX, ampX, noiX, mX)
+    ll, dl, da, dn, dm = g.loglike_grad()
+    assert abs(ll - ll_o) <= tol * (1 + abs(ll_o))
+    for got, want in ((dl, dl_o), (da, da_o), (dn, dn_o), (dm, dm_o)):
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= tol * (1 + np.abs(want).max()) * 100, (np.abs(got - want).max(), np.abs(want).max())
+    ll2, dl2, da2, dn2, dm2 = g.loglike_grad()                # repeated: bit-identical
+    assert np.array_equal(dl, dl2) and np.array_equal(da, da2) and np.array_equal(dn, dn2) and np.array_equal(dm, dm2)
+    mu, var = g.predict(X[:, :3], lamX[:, :3], ampX[:3], mX[:3])   # the handle's factor is untouched
+    mu_o, var_o = O.nonstationary_mean_and_var(post, X[:, :3], lamX[:, :3], ampX[:3], mean_s=mX[:3])
+    assert np.abs(mu - mu_o).max() <= tol * (1 + np.abs(mu_o).max()) * 10 and np.abs(var - var_o).max() <= tol * 10
+    g.close()
+
+
 @pytest.mark.parametrize("disc", [False, True])
 def test_nonstationary_gp_append(api, O, disc):
     """augment_dataset! (src/types/problem.jl:191-198) on a nonstationary posterior = a fresh fit on all points with the latent models
@@ -2073,7 +2109,7 @@ def test_nonstationary_gp_discrete_errors_and_host_mirror(api, O):
     assert np.allclose(acq, want, rtol=0, atol=1e-12) and am == int(np.argmax(want))
     g = posts[0].gp
     for call in (lambda: api.GP.update(g, [1.0, 1.0], 1.0, 0.1), lambda: api.GP.predict(g, Xs), lambda: api.GP.append(g, X[:, :1], [0.0]),
-                 lambda: api.GP.predict_grad(g, Xs), lambda: g.predict_cov(Xs), lambda: g.loglike_grad(),
+                 lambda: api.GP.predict_grad(g, Xs), lambda: g.predict_cov(Xs), lambda: api.GP.loglike_grad(g),
                  lambda: api.acq_ei([[g]], api.Candidates(Xs), [1.0], None, 0.0, None),
                  lambda: g.update(np.zeros((d, N)), np.ones(N), np.ones(N)),             # λ = 0
                  lambda: g.update(np.ones((d, N)), -np.ones(N), np.ones(N))):

@@ -390,3 +390,36 @@ def test_gradient_gp_likelihood_gradient_matches_finite_differences(kernel):
             e[i] = 1e-6 * max(1.0, abs(th[i]))
             fd[i] = (f(th + e) - f(th - e)) / (2 * e[i])
         assert np.abs(g - fd).max() <= 2e-6 * (1 + np.abs(fd).max()), (kernel, d, n, dup, g, fd)
+
+
+@pytest.mark.parametrize("disc", [False, True])
+def test_nonstationary_likelihood_gradient_matches_finite_differences(disc):
+    """oracle.nonstationary_loglike_grad (∂ℓ/∂ of the latent values λ(x_i), α(x_i), σ(x_i), m(x_i) at the training points) against
+    central differences of nonstationary_fit(...).logpdf, with and without a rounded dimension."""
+    rng = np.random.default_rng(3)
+    d, N = 3, 12
+    discrete = np.array([False, True, False]) if disc else None
+    X = rng.uniform(0, 1, (d, N))
+    if disc:
+        X[1] *= 4
+    y = np.sin(3 * X).sum(0)
+    lam, amp, noi, m = rng.uniform(0.3, 0.9, (d, N)), rng.uniform(0.8, 1.3, N), rng.uniform(0.03, 0.1, N), 0.2 * X[0]
+    ll, dl, da, dn, dm = O.nonstationary_loglike_grad(X, y, lam, amp, noi, mean=m, discrete=discrete)
+    f = lambda lam, amp, noi, m: O.nonstationary_fit(X, y, lam, amp, noi, mean=m, discrete=discrete).logpdf   # noqa: E731
+    assert ll == f(lam, amp, noi, m)
+    e = 1e-6
+
+    def fd(arr, idx, which):
+        p, q = arr.copy(), arr.copy()
+        p[idx] += e
+        q[idx] -= e
+        args = {"lam": (p, amp, noi, m), "amp": (lam, p, noi, m), "noi": (lam, amp, p, m), "m": (lam, amp, noi, p)}[which]
+        args2 = {"lam": (q, amp, noi, m), "amp": (lam, q, noi, m), "noi": (lam, amp, q, m), "m": (lam, amp, noi, q)}[which]
+        return (f(*args) - f(*args2)) / (2 * e)
+    for l in range(d):
+        for i in (0, 5, N - 1):
+            assert abs(fd(lam, (l, i), "lam") - dl[l, i]) <= 1e-6 * (1 + abs(dl[l, i]))
+    for i in (0, 4, N - 1):
+        assert abs(fd(amp, i, "amp") - da[i]) <= 1e-6 * (1 + abs(da[i]))
+        assert abs(fd(noi, i, "noi") - dn[i]) <= 1e-6 * (1 + abs(dn[i]))
+        assert abs(fd(m, i, "m") - dm[i]) <= 1e-6 * (1 + abs(dm[i]))
