@@ -22,7 +22,7 @@ if "--child" in sys.argv:
     print(f"mode {os.environ.get('BOSS_CHAIN_TRAIL')} N={N}: p50 {ts[len(ts)//2]*1e3:.4f} ms min {ts[0]*1e3:.4f} max {ts[-1]*1e3:.4f}  logpdf {lps[0]!r}", flush=True)
     sys.exit(0)
 N = sys.argv[1]; reps = sys.argv[2] if len(sys.argv) > 2 else "200"
-modes = os.environ.get("MODES", "0,1")   # (0: one launch per step, 1: main-stream pairs, 2: two-stream gated; mode 3 was a removed experiment).split(",")
+modes = os.environ.get("MODES", "0,1").split(",")   # (0: one launch per step, 1: main-stream pairs, 2: two-stream gated; mode 3 was a removed experiment)
 for m in modes:
     env = dict(os.environ, BOSS_CHAIN_TRAIL=m, PYTHONUNBUFFERED="1")
     r = subprocess.run([sys.executable, os.path.abspath(__file__), N, reps, "--child"], env=env, timeout=300)
